@@ -1,0 +1,135 @@
+/*
+ * ddz_env.h -- C ABI of libddz_hip.so, the MI355X (gfx950) batched Doudizhu engine.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json:north_star:
+ * what the reference reaches through its (absent) pybind modules `env` and `r`
+ * (envi.py:10-13) plus the per-game Python adapter envi.py, re-cut as batched
+ * verbs over T independent tables.  Plain pointers and sizes only: every buffer
+ * is DEVICE memory owned by the caller (PyTorch tensors in the host mirror
+ * doudizhu-rl_amd/envi.py); the library allocates nothing on the device, never
+ * synchronises, and enqueues all work on the hipStream_t passed as `stream`
+ * (void* so that this header needs no HIP include).  All entry points return 0
+ * or a negative DDZ_E* code and never throw.  A handle is not thread-safe.
+ *
+ * Reference citations are relative to /root/reference.
+ */
+#ifndef DDZ_ENV_H
+#define DDZ_ENV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDZ_ABI_VERSION 1
+#define DDZ_NUM_ACTIONS 13527 /* rule_based/utils/card.py:34-159 */
+#define DDZ_ROW 16            /* packed row: int8 counts[15] (3..K,A,2,BJ,CJ; envi.py:122-124) + 1 aux byte */
+#define DDZ_NFIELDS 11
+#define DDZ_TRAJ_BYTES 32
+
+/* error codes */
+#define DDZ_OK 0
+#define DDZ_EINVAL (-1)   /* bad argument / shape / null pointer          */
+#define DDZ_EHANDLE (-2)  /* bad or destroyed handle                       */
+#define DDZ_EHIP (-3)     /* a HIP runtime call failed (see ddz_last_hip_error) */
+#define DDZ_ECAP (-4)     /* row capacity cannot be indexed with int32     */
+#define DDZ_ENODEV (-5)   /* no usable gfx950 device                       */
+
+/* state fields: state is DDZ_NFIELDS arrays of [T][16] bytes, field-major.
+ *   0..2  hand of role 0 up / 1 lord / 2 down (envi.py:24); byte 15 = cards left (envi.py:23)
+ *   3..5  history: cumulative cards played by the role (envi.py:41)
+ *   6..8  recent_handout of the role, zeros for a pass (envi.py:43); byte 15 = category
+ *   9     taken: all cards played (envi.py:40)
+ *   10    meta: [0] role to move, [1] done, [2] winner (0xFF running), [3] i8 last r,
+ *               [4..5] u16 ply, [6] dealt, [8..11] u32 episode                          */
+enum { DDZ_F_HAND0 = 0, DDZ_F_HIST0 = 3, DDZ_F_RECENT0 = 6, DDZ_F_TAKEN = 9, DDZ_F_META = 10 };
+
+/* step modes */
+#define DDZ_STEP_RANDOM 0 /* uniform index into the legal list, engine RNG   (envi.py:79-85 step_random) */
+#define DDZ_STEP_CHOICE 1 /* sel = const int32_t[T], index into each table's legal segment              */
+#define DDZ_STEP_ROWS 2   /* sel = const int8_t[T][16] count rows (envi.py:63-70 step_manual), validated
+                             against the legal segment; no match -> illegal flag, table untouched       */
+
+/* face variants (envi.py:87-96, :165-178, :182-198, :202-217) -> planes P = 4, 7, 9, 6 */
+#define DDZ_FACE_ENV 0
+#define DDZ_FACE_COMPLICATED 1
+#define DDZ_FACE_COOPERATION 2
+#define DDZ_FACE_COOPERATION_SIMPLIFY 3
+
+typedef struct ddz_env ddz_env_t;
+
+int ddz_abi_version(void);
+const char* ddz_strerror(int code);
+/* last hipError_t seen by this library on the calling thread (0 = hipSuccess) */
+int ddz_last_hip_error(void);
+
+/* sizes of the caller-owned device buffers for T tables */
+int64_t ddz_state_bytes(int64_t n_tables);   /* DDZ_NFIELDS * T * 16 */
+int64_t ddz_scratch_bytes(int64_t n_tables); /* per-table query records, counts, scan partials, status */
+int ddz_face_planes(int variant);            /* 4 / 7 / 9 / 6, or DDZ_EINVAL */
+
+/* Replaces `Env(seed=)` construction (envi.py:17-28): binds caller-owned device
+ * buffers to a handle.  `state` must be zero-filled (or hold an exported state);
+ * table t of this handle is global table `table_id_base + t` for the RNG, so a
+ * sharded run deals the same cards whatever the GPU count.                      */
+int ddz_create(ddz_env_t** out, int64_t n_tables, uint64_t seed, uint64_t table_id_base,
+               int device_id, void* state, int64_t state_bytes, void* scratch,
+               int64_t scratch_bytes);
+int ddz_destroy(ddz_env_t* env);
+/* tell the engine that `state` was overwritten behind its back (checkpoint load) */
+int ddz_invalidate(ddz_env_t* env);
+
+/* Replaces Env.reset() + native prepare() (envi.py:30-36, game.py:170-171): clear the
+ * bookkeeping and deal 17/20/17 (lord = role 1 moves first) for every table whose mask
+ * byte is non-zero (mask NULL = all).  Deal/RNG = spec v1.                */
+int ddz_reset(ddz_env_t* env, const uint8_t* table_mask, void* stream);
+
+/* Replaces Env.valid_actions(tensor=False) / r.get_moves (envi.py:98-116) for all tables:
+ * CSR list in ascending canonical action id (pass first when following).
+ *   offsets int32[T+1]; rows int8[row_capacity][16] (byte 15 = category);
+ *   ids int32[row_capacity] canonical action ids, may be NULL.
+ * Writes beyond row_capacity are dropped and status bit 1 is raised.                  */
+int ddz_legal(ddz_env_t* env, int32_t* offsets, int8_t* rows, int32_t* ids,
+              int64_t row_capacity, void* stream);
+
+/* Replaces Env.step_manual / step_random (+ _update) and the native step
+ * (envi.py:38-43, 63-70, 79-85): apply one action per table, taken from the CSR list
+ * produced by ddz_legal for the *current* state.  Outputs may be NULL:
+ *   done u8[T]; reward i8[T] (-1 lord won, +1 farmers won, 0 running: rule_play.py:14);
+ *   illegal u8[T]; traj u8[T][32].  With auto_reset a finished table is
+ *   re-dealt inside the same call (episode + 1).                                       */
+int ddz_step(ddz_env_t* env, int mode, const void* sel, const int32_t* offsets,
+             const int8_t* rows, int auto_reset, uint8_t* done, int8_t* reward,
+             uint8_t* illegal, uint8_t* traj, void* stream);
+
+/* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
+int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
+
+/* Replaces batch_arr2onehot (envi.py:139-146) on device: rows int8[n][16] -> f32 [n][15][4] */
+int ddz_rows_to_onehot(int device_id, const int8_t* rows, int64_t n, float* out, void* stream);
+
+/* Replaces r.get_moves(hand15, last15) (envi.py:111, server/core.py:65, server/CFR.py:55)
+ * for n independent queries: hands/lasts int8[n][16] (byte 15 ignored; `last` all-zero =
+ * lead; a `last` that is no combo of the action space yields an empty list and status
+ * bit 2).  scratch: ddz_scratch_bytes(n) bytes.                                        */
+int ddz_get_moves(int device_id, const int8_t* hands, const int8_t* lasts, int64_t n,
+                  int32_t* offsets, int8_t* rows, int32_t* ids, int64_t row_capacity,
+                  void* scratch, int64_t scratch_bytes, void* stream);
+
+/* The lock-step loop of Game.play under a random policy (game.py:169-181 with
+ * envi.py:79-85), n_iters iterations of {legal, step_random(auto_reset)} enqueued
+ * back to back.  stats (device, int64[4], may be NULL) accumulates
+ * {plies, finished episodes, total legal rows, lord wins}; traj (may be NULL) is
+ * u8[n_iters][T][32].                                                                  */
+int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
+                       int32_t* ids, int64_t row_capacity, int64_t* stats, uint8_t* traj,
+                       void* stream);
+
+/* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
+ * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */
+int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

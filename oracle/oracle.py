@@ -1,0 +1,163 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  See oracle/ddz_oracle.h for what is pinned against the reference
+and what is "parity unpinned".
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NUM_ACTIONS = 13527
+ROW = 16
+NFIELDS = 11
+TR_BYTES = 32
+STEP_RANDOM, STEP_CHOICE, STEP_ROWS = 0, 1, 2
+PLANES = (4, 7, 9, 6)
+
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(HERE, "libddz_oracle.so")
+    src = os.path.join(HERE, "ddz_oracle.c")
+    hdr = os.path.join(HERE, "ddz_oracle.h")
+    stale = (not os.path.exists(so)) or any(
+        os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "libddz_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        p = C.c_void_p
+        L.ddzo_init.restype = None
+        L.ddzo_action_table.argtypes = [p, p]
+        L.ddzo_beats.argtypes = [C.c_int, C.c_int]
+        L.ddzo_beats.restype = C.c_int
+        L.ddzo_lookup.argtypes = [p]
+        L.ddzo_lookup.restype = C.c_int
+        L.ddzo_legal.argtypes = [p, p, p, C.c_int]
+        L.ddzo_legal.restype = C.c_int
+        L.ddzo_philox4x32_10.argtypes = [p, p, p]
+        L.ddzo_env_reset.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, p]
+        L.ddzo_env_legal.argtypes = [p, C.c_int64, p, p, p, C.c_int64]
+        L.ddzo_env_legal.restype = C.c_int64
+        L.ddzo_env_step.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int, p, p, p,
+                                    C.c_int, p, p, p, p]
+        L.ddzo_planes.argtypes = [C.c_int]
+        L.ddzo_planes.restype = C.c_int
+        L.ddzo_env_observe.argtypes = [p, C.c_int64, C.c_int, p]
+        L.ddzo_rows_to_onehot.argtypes = [p, C.c_int64, p]
+        L.ddzo_rollout_random.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, p, p]
+        L.ddzo_rollout_random.restype = C.c_int64
+        L.ddzo_init()
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def action_table():
+    rows = np.zeros((NUM_ACTIONS, ROW), np.int8)
+    info = np.zeros((NUM_ACTIONS, 4), np.uint8)
+    lib().ddzo_action_table(_ptr(rows), _ptr(info))
+    return rows, info
+
+
+def beats(a, b):
+    return bool(lib().ddzo_beats(int(a), int(b)))
+
+
+def lookup(counts15):
+    c = np.ascontiguousarray(counts15, np.int8)
+    return lib().ddzo_lookup(_ptr(c))
+
+
+def legal(hand15, last15=None):
+    """sorted canonical ids of get_mask(hand, action_space, last)."""
+    h = np.ascontiguousarray(hand15, np.int8)
+    l = None if last15 is None else np.ascontiguousarray(last15, np.int8)
+    ids = np.zeros(NUM_ACTIONS, np.int32)
+    n = lib().ddzo_legal(_ptr(h), _ptr(l), _ptr(ids), NUM_ACTIONS)
+    if n < 0:
+        raise ValueError("last is not a combo of the action space (or bad hand)")
+    return ids[:n].copy()
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, np.uint32)
+    k = np.asarray(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    lib().ddzo_philox4x32_10(_ptr(c), _ptr(k), _ptr(o))
+    return o
+
+
+class OracleEnv:
+    """Batched CPU environment with the same state layout as the device engine."""
+
+    def __init__(self, n_tables, seed=0, gid_base=0):
+        self.T = int(n_tables)
+        self.seed = int(seed)
+        self.gid_base = int(gid_base)
+        self.state = np.zeros(self.T * NFIELDS * ROW, np.uint8)
+        self.offsets = np.zeros(self.T + 1, np.int32)
+        self.cap = self.T * 512
+        self.rows = np.zeros((self.cap, ROW), np.int8)
+        self.ids = np.zeros(self.cap, np.int32)
+        self.total = 0
+
+    def field(self, f):
+        return self.state.reshape(NFIELDS, self.T, ROW)[f]
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().ddzo_env_reset(_ptr(self.state), self.T, self.seed, self.gid_base, _ptr(m))
+
+    def legal(self):
+        self.total = lib().ddzo_env_legal(_ptr(self.state), self.T, _ptr(self.offsets),
+                                          _ptr(self.rows), _ptr(self.ids), self.cap)
+        assert self.total <= self.cap
+        return self.offsets, self.rows[:self.total], self.ids[:self.total]
+
+    def step(self, mode=STEP_RANDOM, sel=None, auto_reset=True, want_traj=False):
+        done = np.zeros(self.T, np.uint8)
+        reward = np.zeros(self.T, np.int8)
+        illegal = np.zeros(self.T, np.uint8)
+        traj = np.zeros((self.T, TR_BYTES), np.uint8) if want_traj else None
+        if mode == STEP_CHOICE:
+            sel = np.ascontiguousarray(sel, np.int32)
+        elif mode == STEP_ROWS:
+            sel = np.ascontiguousarray(sel, np.int8)
+        lib().ddzo_env_step(_ptr(self.state), self.T, self.seed, self.gid_base, mode, _ptr(sel),
+                            _ptr(self.offsets), _ptr(self.rows), int(auto_reset), _ptr(done),
+                            _ptr(reward), _ptr(illegal), _ptr(traj))
+        return done, reward, illegal, traj
+
+    def observe(self, variant):
+        out = np.zeros((self.T, PLANES[variant], 15, 4), np.float32)
+        lib().ddzo_env_observe(_ptr(self.state), self.T, variant, _ptr(out))
+        return out
+
+    def rollout_random(self, n_iters):
+        sl = C.c_int64(0)
+        ep = C.c_int64(0)
+        plies = lib().ddzo_rollout_random(_ptr(self.state), self.T, self.seed, self.gid_base,
+                                          int(n_iters), C.byref(sl), C.byref(ep))
+        return plies, sl.value, ep.value
+
+
+def rows_to_onehot(rows):
+    r = np.ascontiguousarray(rows, np.int8).reshape(-1, ROW)
+    out = np.zeros((r.shape[0], 15, 4), np.float32)
+    lib().ddzo_rows_to_onehot(_ptr(r), r.shape[0], _ptr(out))
+    return out
