@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/s of the batched lock-step engine (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+A "step" is one lock-step iteration of the hot path over all tables of this rank:
+legal-move enumeration into the CSR list + random-policy action application with
+auto-reset (configs[1]: 4096 tables per MI355X, random policy, legal-move list only).
+Weak scaling: every GPU runs 4096 tables of the global id range; for N > 1 the packed
+trajectories of the K steps are all-gathered over RCCL inside the timed region (the only
+exchange the path has).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def cpu_baseline(tables, budget_s):
+    """Oracle (CPU port of the same rules/env) on the host cores of this box, 1 thread."""
+    from oracle import oracle
+    env = oracle.OracleEnv(tables, seed=0)
+    env.reset()
+    t0 = time.perf_counter()
+    plies, _, _ = env.rollout_random(3)
+    per_iter = (time.perf_counter() - t0) / 3
+    n = max(3, min(2000, int(budget_s / max(per_iter, 1e-6))))
+    t0 = time.perf_counter()
+    plies, legal, eps = env.rollout_random(n)
+    dt = time.perf_counter() - t0
+    return {"value": plies / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} lock-step iterations x {tables} tables (oracle/ddz_oracle.c, dense "
+                      f"13,527-row scan per state), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--tables", type=int, default=4096, help="tables per GPU (configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("doudizhu-rl_amd")
+    ddist = importlib.import_module("doudizhu-rl_amd.dist")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    T = a.tables
+    total_tables = T * world
+    _, base = ddist.shard_tables(total_tables, rank, world)
+    env = pkg.BatchedEnv(T, seed=0, device=dev, table_id_base=base, want_ids=False)
+    env.reset()
+    K, W = a.steps, a.warmup
+    traj = torch.zeros((K, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    env.rollout_random(W)
+    if world > 1:  # warm the collective too
+        ddist.gather_trajectories(traj[: max(1, min(K, 8))])
+    env.stats()  # clears the accumulators (sync)
+    barrier()
+    t0 = time.perf_counter()
+    env.rollout_random(K, traj=traj)
+    if world > 1:
+        gathered = ddist.gather_trajectories(traj)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        assert gathered.shape == (K, total_tables, pkg.TRAJ_BYTES)
+    st = env.stats()
+    status = env.status()
+    assert st["plies"] == T * K and status == 0, (st, status)
+    mean_a = st["legal_rows"] / max(1, st["plies"])
+
+    # per-kernel durations (HIP events between the launches, same stream, same workload)
+    ms_enum, ms_step = env.rollout_random_timed(min(K, 2000))
+    n_timed = min(K, 2000)
+    st2 = env.stats()
+    mean_a2 = st2["legal_rows"] / max(1, st2["plies"])
+    # algorithmic bytes per launch (DESIGN.md "Kernels"): per table
+    #   enumerate: 16 query record + 4 count + 4 offset out + 16*A rows out
+    #   step:      meta 16 + offsets 8 + row 16 + hand/hist/taken 48 + next hand 16 + recent 16 in,
+    #              hand/hist/taken/recent/meta 80 + query 16 + count/scan 8 out
+    b_enum = T * (24 + 16 * mean_a2)
+    b_step = T * 224
+    dur_enum = ms_enum / n_timed * 1e-3
+    dur_step = ms_step / n_timed * 1e-3
+    dominant = "k_enum" if dur_enum >= dur_step else "k_step"
+    ach = (b_enum / dur_enum if dominant == "k_enum" else b_step / dur_step) / 1e9
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(dominant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "env steps/sec (batched tables)", "value": total_tables * K / dt,
+            "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), CSR legal-move "
+                                   "list only (no NN), auto-reset; BASELINE.json configs[1]",
+                       "tables_per_gpu": T, "total_tables": total_tables,
+                       "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
+                       "trajectory_gather": world > 1},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
+                         "us_per_launch": {"k_enum": dur_enum * 1e6, "k_step": dur_step * 1e6},
+                         "algorithmic_bytes_per_launch": {"k_enum": b_enum, "k_step": b_step}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""doudizhu-rl_amd: MI355X-native batched Doudizhu environment (hot path of
+charleschen003/doudizhu-rl: deal, legal-move enumeration, action application,
+terminal/reward, state encoding).  HIP kernels + C ABI under csrc/, host mirror of the
+reference's envi.py here.  Import never touches the GPU; using the engine without the
+built library or without an MI355X raises (there is no CPU fallback)."""
+from ._lib import DdzError  # noqa: F401
+from .engine import (BatchedEnv, FACE_PLANES, NUM_ACTIONS, STEP_CHOICE, STEP_RANDOM,  # noqa: F401
+                     STEP_ROWS, TRAJ_BYTES, get_moves, rows_to_onehot)
+from .envi import Env, EnvComplicated, EnvCooperation, EnvCooperationSimplify  # noqa: F401

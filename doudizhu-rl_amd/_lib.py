@@ -1,0 +1,72 @@
+"""ctypes binding of libddz_hip.so (C ABI: include/ddz_env.h).
+
+There is NO CPU fallback: if the library is missing or no MI355X is visible, every
+product entry point raises.  (The CPU oracle under oracle/ is test infrastructure and is
+never imported from here.)"""
+import ctypes as C
+import os
+
+from .build import LIB
+
+_lib = None
+
+SYMBOLS = {
+    # name: (restype, argtypes)
+    "ddz_abi_version": (C.c_int, []),
+    "ddz_strerror": (C.c_char_p, [C.c_int]),
+    "ddz_last_hip_error": (C.c_int, []),
+    "ddz_state_bytes": (C.c_int64, [C.c_int64]),
+    "ddz_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "ddz_face_planes": (C.c_int, [C.c_int]),
+    "ddz_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_uint64, C.c_uint64, C.c_int,
+                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "ddz_destroy": (C.c_int, [C.c_void_p]),
+    "ddz_invalidate": (C.c_int, [C.c_void_p]),
+    "ddz_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_legal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddz_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddz_rows_to_onehot": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ddz_get_moves": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddz_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_rollout_random_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
+    "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+
+class DdzError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libddz_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise DdzError(
+                f"{LIB} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError = header/library mismatch, loud
+            fn.restype = res
+            fn.argtypes = args
+        if L.ddz_abi_version() != 1:
+            raise DdzError("libddz_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.ddz_strerror(rc).decode()
+        if rc == -3:
+            msg += f" (hipError {L.ddz_last_hip_error()})"
+        raise DdzError(f"libddz_hip: {msg}")

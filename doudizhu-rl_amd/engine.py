@@ -1,0 +1,259 @@
+"""BatchedEnv: T independent Doudizhu tables advanced in lock-step on one MI355X.
+
+Host-side mirror of the reference's env adapter (envi.py:16-161) re-cut as batched verbs.
+PyTorch owns every buffer (state, scratch, CSR list, outputs); the HIP library
+(csrc/, C ABI include/ddz_env.h) is handed raw device pointers and the current stream.
+Nothing here computes game logic on the CPU, and nothing falls back to it.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DdzError, check
+
+ROW = 16
+NFIELDS = 11
+TRAJ_BYTES = 32
+NUM_ACTIONS = 13527
+STEP_RANDOM, STEP_CHOICE, STEP_ROWS = 0, 1, 2
+FACE_PLANES = (4, 7, 9, 6)  # Env, EnvComplicated, EnvCooperation, EnvCooperationSimplify
+F_HAND0, F_HIST0, F_RECENT0, F_TAKEN, F_META = 0, 3, 6, 9, 10
+# a 20-card hand never has more than this many legal moves (tests/test_rules_bounds.py);
+# the default row capacity is T * MAX_LEGAL_PER_TABLE so the CSR list cannot overflow.
+MAX_LEGAL_PER_TABLE = 512
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise DdzError("no MI355X visible (torch.cuda.is_available() is False): the engine has "
+                       "no CPU fallback")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise DdzError(f"device must be a cuda (ROCm) device, got {dev}")
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class BatchedEnv:
+    """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
+
+    def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
+                 want_ids=True):
+        self.lib = _lib.lib()
+        self.device = _require_gpu(device)
+        self.T = int(n_tables)
+        if self.T <= 0:
+            raise ValueError("n_tables must be positive")
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.table_id_base = int(table_id_base)
+        self.cap = int(row_capacity) if row_capacity is not None else self.T * MAX_LEGAL_PER_TABLE
+        if self.cap > 0x7FFFFFFF:
+            raise ValueError("row capacity must be indexable with int32")
+        d = self.device
+        self.state = torch.zeros(self.lib.ddz_state_bytes(self.T), dtype=torch.uint8, device=d)
+        self.scratch = torch.zeros(self.lib.ddz_scratch_bytes(self.T), dtype=torch.uint8, device=d)
+        self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
+        self.rows = torch.zeros((self.cap, ROW), dtype=torch.int8, device=d)
+        self.ids = torch.zeros(self.cap, dtype=torch.int32, device=d) if want_ids else None
+        self.done = torch.zeros(self.T, dtype=torch.uint8, device=d)
+        self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
+        self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
+        self._stats = torch.zeros(4, dtype=torch.int64, device=d)
+        self._legal_fresh = False
+        h = C.c_void_p()
+        check(self.lib.ddz_create(C.byref(h), self.T, self.seed, self.table_id_base, d.index,
+                                  _p(self.state), self.state.numel(), _p(self.scratch),
+                                  self.scratch.numel()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ddz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- views of the packed state ([T,16] int8/uint8, zero-copy) ----
+    def field(self, f):
+        return self.state.view(NFIELDS, self.T, ROW)[f]
+
+    @property
+    def role(self):
+        return self.field(F_META)[:, 0]
+
+    def hands(self):
+        return self.state.view(NFIELDS, self.T, ROW)[F_HAND0:F_HAND0 + 3]
+
+    # ---- verbs ----
+    def reset(self, mask=None):
+        """Env.reset() + prepare() (envi.py:30-36, game.py:170-171) for masked tables."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.T:
+                raise ValueError("mask must have one byte per table")
+        check(self.lib.ddz_reset(self._h, _p(mask), _stream(self.device)))
+        self._legal_fresh = False
+
+    def legal(self):
+        """CSR legal-move lists of all tables (envi.py:98-116 valid_actions(tensor=False)).
+        Returns (offsets[T+1] i32, rows[cap,16] i8, ids[cap] i32 | None); only the first
+        offsets[T] rows are meaningful.  No host sync."""
+        check(self.lib.ddz_legal(self._h, _p(self.offsets), _p(self.rows), _p(self.ids), self.cap,
+                                 _stream(self.device)))
+        self._legal_fresh = True
+        return self.offsets, self.rows, self.ids
+
+    def _need_legal(self):
+        if not self._legal_fresh:
+            self.legal()
+
+    def step(self, sel=None, mode=STEP_CHOICE, auto_reset=True, traj=None):
+        """Apply one action per table (envi.py:63-70 step_manual / :79-85 step_random).
+        mode STEP_RANDOM: sel ignored; STEP_CHOICE: sel int32[T] index into each legal
+        segment; STEP_ROWS: sel int8[T,16] count rows.  Returns (done u8[T], r i8[T],
+        illegal u8[T]); r = -1 lord won, +1 farmers won (rule_play.py:14)."""
+        self._need_legal()
+        if mode == STEP_CHOICE:
+            sel = sel.to(device=self.device, dtype=torch.int32).contiguous()
+            if sel.numel() != self.T:
+                raise ValueError("choice must have one index per table")
+        elif mode == STEP_ROWS:
+            sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
+            if tuple(sel.shape) != (self.T, ROW):
+                raise ValueError("rows must be [T,16] int8")
+        elif mode != STEP_RANDOM:
+            raise ValueError("bad step mode")
+        if traj is not None and (traj.dtype != torch.uint8 or traj.numel() != self.T * TRAJ_BYTES
+                                 or not traj.is_contiguous()):
+            raise ValueError("traj must be a contiguous uint8 [T,32] tensor")
+        check(self.lib.ddz_step(self._h, mode, _p(sel) if mode != STEP_RANDOM else None,
+                                _p(self.offsets), _p(self.rows), int(bool(auto_reset)),
+                                _p(self.done), _p(self.reward), _p(self.illegal), _p(traj),
+                                _stream(self.device)))
+        self._legal_fresh = False
+        return self.done, self.reward, self.illegal
+
+    def step_random(self, auto_reset=True, traj=None):
+        return self.step(None, STEP_RANDOM, auto_reset, traj)
+
+    def observe(self, variant=3, out=None):
+        """`face` of every table: f32 [T,P,15,4] (envi.py:87-96,165-217)."""
+        P = FACE_PLANES[variant]
+        if out is None:
+            out = torch.empty((self.T, P, 15, 4), dtype=torch.float32, device=self.device)
+        check(self.lib.ddz_observe(self._h, int(variant), _p(out), _stream(self.device)))
+        return out
+
+    def legal_onehot(self):
+        """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
+        self._need_legal()
+        total = int(self.offsets[-1].item())
+        return rows_to_onehot(self.rows[:total])
+
+    def rollout_random(self, n_iters, traj=None):
+        """n_iters lock-step iterations of {legal, step_random(auto_reset)} (game.py:169-181)."""
+        if traj is not None and (traj.dtype != torch.uint8 or not traj.is_contiguous()
+                                 or traj.numel() != n_iters * self.T * TRAJ_BYTES):
+            raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
+        check(self.lib.ddz_rollout_random(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
+                                          _p(self.ids), self.cap, _p(self._stats), _p(traj),
+                                          _stream(self.device)))
+        self._legal_fresh = False
+
+    def rollout_random_timed(self, n_iters):
+        """Same loop with a hipEvent between the kernels; returns (ms_enumerate, ms_step)
+        summed over n_iters.  Synchronises; measurement aid for bench.py."""
+        ms = (C.c_double * 2)()
+        check(self.lib.ddz_rollout_random_timed(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
+                                                _p(self.ids), self.cap, ms, _stream(self.device)))
+        self._legal_fresh = False
+        return ms[0], ms[1]
+
+    def stats(self):
+        """{plies, episodes, legal_rows, lord_wins} accumulated so far (host sync)."""
+        check(self.lib.ddz_read_stats(self._h, _p(self._stats), _stream(self.device)))
+        p, e, l, w = self._stats.tolist()
+        return {"plies": p, "episodes": e, "legal_rows": l, "lord_wins": w}
+
+    def status(self):
+        """device status word (0 = healthy); host sync."""
+        out = C.c_int32(0)
+        check(self.lib.ddz_status(self._h, C.byref(out), _stream(self.device)))
+        return out.value
+
+    # ---- checkpoint (the whole env is one byte tensor) ----
+    def state_export(self):
+        return self.state.clone()
+
+    def state_import(self, state):
+        if state.numel() != self.state.numel():
+            raise ValueError("state size mismatch")
+        self.state.copy_(state.to(self.device).view(-1))
+        check(self.lib.ddz_invalidate(self._h))
+        self._legal_fresh = False
+
+
+def rows_to_onehot(rows):
+    """batch_arr2onehot (envi.py:139-146) on device: int8 [n,16] -> f32 [n,15,4]."""
+    L = _lib.lib()
+    dev = _require_gpu(rows.device)
+    rows = rows.to(torch.int8).contiguous()
+    n = rows.shape[0]
+    out = torch.empty((n, 15, 4), dtype=torch.float32, device=dev)
+    if n:
+        check(L.ddz_rows_to_onehot(dev.index, _p(rows), n, _p(out), _stream(dev)))
+    return out
+
+
+def get_moves(hands, lasts, want_ids=True, row_capacity=None):
+    """Batched r.get_moves(hand15, last15) (envi.py:111): hands/lasts int8 [n,15|16] on the
+    GPU.  Returns (offsets[n+1] i32, rows[total,16] i8, ids[total] i32 | None); one host sync
+    to trim the outputs."""
+    L = _lib.lib()
+    dev = _require_gpu(hands.device)
+
+    def pad(x):
+        x = x.to(device=dev, dtype=torch.int8)
+        if x.shape[1] == 15:
+            x = torch.nn.functional.pad(x, (0, 1))
+        return x.contiguous()
+
+    hands, lasts = pad(hands), pad(lasts)
+    n = hands.shape[0]
+    if lasts.shape[0] != n:
+        raise ValueError("hands and lasts must have the same length")
+    cap = int(row_capacity) if row_capacity is not None else min(n * NUM_ACTIONS, 0x7FFFFFFF)
+    offsets = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(L.ddz_scratch_bytes(n), dtype=torch.uint8, device=dev)
+
+    def run(capacity):
+        rows = torch.empty((max(capacity, 1), ROW), dtype=torch.int8, device=dev)
+        ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev) if want_ids else None
+        check(L.ddz_get_moves(dev.index, _p(hands), _p(lasts), n, _p(offsets), _p(rows), _p(ids),
+                              capacity, _p(scratch), scratch.numel(), _stream(dev)))
+        return rows, ids
+
+    if row_capacity is None and n * NUM_ACTIONS > (1 << 22):
+        run(0)  # sizes only: offsets are exact whatever the capacity
+        cap = int(offsets[-1].item())
+        scratch.zero_()
+    rows, ids = run(cap)
+    total = int(offsets[-1].item())
+    if total > cap:
+        raise DdzError(f"row capacity {cap} too small for {total} rows")
+    bad = int(scratch.view(torch.int32)[(scratch.numel() - 256) // 4].item()) & 4
+    if bad:
+        raise ValueError("a `last` vector is not a combo of the action space")
+    return offsets, rows[:total], (ids[:total] if want_ids else None)

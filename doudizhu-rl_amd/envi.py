@@ -1,0 +1,161 @@
+"""Drop-in for the reference's envi.py: the same class names, methods, shapes and dtypes
+(`Env`, `EnvComplicated`, `EnvCooperation`, `EnvCooperationSimplify`; envi.py:16-217), backed
+by a one-table BatchedEnv on the MI355X instead of the absent pybind modules `env` / `r`
+(envi.py:10-13).  This is the N = 1 compatibility view for the existing game.py / dqn.py
+loop; throughput comes from BatchedEnv, which these classes wrap.
+
+Differences that cannot be avoided (documented in DESIGN.md): the deal / RNG and the two
+probability planes of `face` are this repo's spec v1 because the native code that defined
+them is not in the reference; step_auto (the native rule-based opponent) is not built yet.
+"""
+import collections
+import random
+
+import numpy as np
+import torch
+
+from . import config as conf
+from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE,
+                     rows_to_onehot)
+
+
+class Env:
+    FACE_VARIANT = 0  # envi.py:87-96: [hand, taken, prob1, prob2]
+
+    def __init__(self, debug=False, seed=None, device=None):
+        self.device = torch.device(device) if device is not None else conf.DEVICE
+        # `if seed:` in the reference (envi.py:18-21): seed 0 / None -> unseeded
+        self._seed = int(seed) if seed else random.getrandbits(63)
+        self._b = BatchedEnv(1, seed=self._seed, device=self.device)
+        self.debug = debug
+        self._clear()
+
+    # ---- bookkeeping mirrors (envi.py:22-27); values are read back from the device ----
+    def _clear(self):
+        self.taken = np.zeros((15,))
+        self.left = np.array([17, 20, 17], dtype=int)
+        self.history = collections.defaultdict(lambda: np.zeros((15,)))
+        self.recent_handout = collections.defaultdict(lambda: np.zeros((15,)))
+        self.old_cards = dict()
+
+    def _sync(self):
+        s = self._b.state.view(11, 16).cpu().numpy()
+        self.taken = s[F_TAKEN, :15].astype(float)
+        self.left = s[F_HAND0:F_HAND0 + 3, 15].astype(int)
+        for r in range(3):
+            self.history[r] = s[F_HIST0 + r, :15].astype(float)
+            self.recent_handout[r] = s[F_RECENT0 + r, :15].astype(int)
+        self._meta = s[F_META]
+        self._hands = s[F_HAND0:F_HAND0 + 3, :15].astype(int)
+
+    def reset(self):
+        """envi.py:30-36: clears the adapter state; cards are dealt by prepare()."""
+        self._clear()
+
+    def prepare(self):
+        """native shuffle + deal + lord selection (game.py:171); deal = spec v1."""
+        self._b.reset()
+        self._sync()
+
+    # ---- native getters used by the callers ----
+    def get_role_ID(self):
+        return int(self._meta[0]) + 1  # 1-based (envi.py:64)
+
+    def get_curr_handcards(self):
+        return self.arr2cards(self._hands[int(self._meta[0])])
+
+    def get_last_two_cards(self):
+        role = int(self._meta[0])
+        prev = self.arr2cards(self.recent_handout[(role + 2) % 3].astype(int))
+        prevprev = self.arr2cards(self.recent_handout[(role + 1) % 3].astype(int))
+        return [list(prev), list(prevprev)]
+
+    # ---- stepping ----
+    def _apply(self, idx):
+        role = self.get_role_ID() - 1
+        self.old_cards[role] = self.get_curr_handcards()
+        done, r, illegal = self._b.step(torch.tensor([idx], dtype=torch.int32), STEP_CHOICE,
+                                        auto_reset=False)
+        if int(illegal.item()):
+            raise ValueError("illegal action for the current state")
+        res = (int(r.item()), bool(done.item()), None)
+        self._sync()
+        if self.debug:
+            print('role {} plays {}, left {}'.format(
+                role, self.cards2str(self.arr2cards(self.recent_handout[role].astype(int))), self.left))
+        return res
+
+    def _find(self, arr):
+        offsets, rows, _ = self._b.legal()
+        n = int(offsets[1].item())
+        want = torch.as_tensor(np.asarray(arr, dtype=np.int8), device=self.device)
+        hit = (rows[:n, :15] == want).all(dim=1).nonzero()
+        if hit.numel() == 0:
+            raise ValueError("illegal action for the current state")
+        return int(hit[0].item())
+
+    def step_manual(self, onehot_cards):
+        """envi.py:63-70: 15x4 thermometer -> (r, done, _); r -1 lord wins / +1 farmers."""
+        return self._apply(self._find(self.onehot2arr(onehot_cards)))
+
+    def step_auto(self):
+        raise NotImplementedError(
+            "step_auto is the native rule-based opponent of the absent `env` module "
+            "(envi.py:72-77); it is row N1 of SURVEY.md section 8f and not built yet")
+
+    def step_random(self):
+        """envi.py:79-85 with Python's global `random` as in the reference."""
+        offsets, _, _ = self._b.legal()
+        return self._apply(random.randrange(int(offsets[1].item())))
+
+    # ---- observations ----
+    @property
+    def face(self):
+        return self._b.observe(self.FACE_VARIANT)[0]
+
+    def valid_actions(self, tensor=True):
+        """envi.py:98-116: f32 [A,15,4] on the device, or a list of A int[15] arrays."""
+        offsets, rows, _ = self._b.legal()
+        n = int(offsets[1].item())
+        if tensor:
+            return rows_to_onehot(rows[:n])
+        return [a for a in rows[:n, :15].cpu().numpy().astype(int)]
+
+    # ---- codecs (envi.py:118-161), host-side like the reference's ----
+    @classmethod
+    def arr2cards(cls, arr):
+        arr = np.asarray(arr, dtype=int)
+        return np.repeat(np.arange(3, 18), arr[:15])
+
+    @classmethod
+    def cards2arr(cls, cards):
+        arr = np.zeros((15,), dtype=int)
+        for card in cards:
+            arr[int(card) - 3] += 1
+        return arr
+
+    @classmethod
+    def batch_arr2onehot(cls, batch_arr):
+        arr = np.asarray(batch_arr).reshape(len(batch_arr), 15)
+        return (arr[:, :, None] > np.arange(4)[None, None, :]).astype(int)
+
+    @classmethod
+    def onehot2arr(cls, onehot_cards):
+        if torch.is_tensor(onehot_cards):
+            onehot_cards = onehot_cards.detach().cpu().numpy()
+        return np.asarray(onehot_cards).reshape(15, 4).sum(axis=1).astype(int)
+
+    def cards2str(self, cards):
+        return [conf.DICT[int(i)] for i in cards]
+
+
+class EnvComplicated(Env):
+    FACE_VARIANT = 1  # envi.py:165-178: + history of (role-1, role, role+1)
+
+
+class EnvCooperation(Env):
+    FACE_VARIANT = 2  # envi.py:182-198: + history + recent handouts of (role-1, role-2)
+
+
+class EnvCooperationSimplify(Env):
+    FACE_VARIANT = 3  # envi.py:202-217: hand, taken, recent handouts, probs

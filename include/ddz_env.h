@@ -125,9 +125,23 @@ int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t
                        int32_t* ids, int64_t row_capacity, int64_t* stats, uint8_t* traj,
                        void* stream);
 
+/* Measurement aid: the same loop with a hipEvent between the kernels, on `stream`.
+ * ms (HOST, double[2]) receives the summed durations of the enumerate and of the step
+ * kernels; synchronises the stream.  Used by bench.py for the roofline figures.           */
+int ddz_rollout_random_timed(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
+                             int32_t* ids, int64_t row_capacity, double* ms, void* stream);
+
+/* stats (device, int64[4]) += {plies, finished episodes, legal rows, lord wins} accumulated by
+ * ddz_step / ddz_legal since the last read; the internal accumulators are cleared.        */
+int ddz_read_stats(ddz_env_t* env, int64_t* stats, void* stream);
+
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */
 int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);
+
+/* test hook: CardGroup.to_cardgroup (card.py:327-335) of arbitrary count rows int8[n][16] ->
+ * out u32[n] = category | value << 8 | len << 16, or 0xFF when the row is no combo.       */
+int ddz_debug_classify(int device_id, const int8_t* rows, int64_t n, uint32_t* out, void* stream);
 
 #ifdef __cplusplus
 }
