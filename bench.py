@@ -80,7 +80,7 @@ def main():
     env.rollout_random(W)
     if world > 1:  # warm the collective too
         ddist.gather_trajectories(traj[: max(1, min(K, 8))])
-    env.stats()  # clears the accumulators (sync)
+    s0 = env.stats()  # cumulative counters so far (sync)
     barrier()
     t0 = time.perf_counter()
     env.rollout_random(K, traj=traj)
@@ -93,26 +93,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         assert gathered.shape == (K, total_tables, pkg.TRAJ_BYTES)
-    st = env.stats()
+    s1 = env.stats()
+    st = {k: s1[k] - s0[k] for k in s1}
     status = env.status()
     assert st["plies"] == T * K and status == 0, (st, status)
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
-    # per-kernel durations (HIP events between the launches, same stream, same workload)
-    ms_enum, ms_step = env.rollout_random_timed(min(K, 2000))
+    # duration of the dominant kernel (one fused k_table launch per lock-step iteration):
+    # HIP events between the launches, same stream, same workload
     n_timed = min(K, 2000)
-    st2 = env.stats()
-    mean_a2 = st2["legal_rows"] / max(1, st2["plies"])
-    # algorithmic bytes per launch (DESIGN.md "Kernels"): per table
-    #   enumerate: 16 query record + 4 count + 4 offset out + 16*A rows out
-    #   step:      meta 16 + offsets 8 + row 16 + hand/hist/taken 48 + next hand 16 + recent 16 in,
-    #              hand/hist/taken/recent/meta 80 + query 16 + count/scan 8 out
-    b_enum = T * (24 + 16 * mean_a2)
-    b_step = T * 224
-    dur_enum = ms_enum / n_timed * 1e-3
-    dur_step = ms_step / n_timed * 1e-3
-    dominant = "k_enum" if dur_enum >= dur_step else "k_step"
-    ach = (b_enum / dur_enum if dominant == "k_enum" else b_step / dur_step) / 1e9
+    ms_table, _ = env.rollout_random_timed(n_timed)
+    s2 = env.stats()
+    mean_a2 = (s2["legal_rows"] - s1["legal_rows"]) / max(1, s2["plies"] - s1["plies"])
+    # algorithmic bytes per launch (DESIGN.md "Kernels"), per table:
+    #   in : 176 state rows + 8 (list size, scan offset)      out: 176 state rows + 4 CSR offset
+    #        + 16*A legal rows + 8 (next list size, scan offset)
+    b_table = T * (372 + 16 * mean_a2)
+    dur_table = ms_table / n_timed * 1e-3
+    dominant = "k_table"
+    ach = b_table / dur_table / 1e9
     traffic = None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
@@ -134,8 +133,8 @@ def main():
                        "trajectory_gather": world > 1},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
-                         "us_per_launch": {"k_enum": dur_enum * 1e6, "k_step": dur_step * 1e6},
-                         "algorithmic_bytes_per_launch": {"k_enum": b_enum, "k_step": b_step}},
+                         "us_per_launch": dur_table * 1e6,
+                         "algorithmic_bytes_per_launch": b_table},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)

@@ -199,67 +199,6 @@ __device__ __forceinline__ uint32_t value_gate(const Follow& f, int c) {
   return c == f.lc ? gt_mask(f.lv) : 0u;
 }
 
-// ---- closed-form size of the legal list (one thread per table) ----------------------
-// Must equal what the wave enumerator emits; k_enum cross-checks and raises status bit 0.
-__device__ inline int count_legal(uint64_t hand, uint32_t info) {
-  if (hand == 0) return 0;  // utils.py:48-49
-  const Follow f = follow_of(info);
-  const Masks m = masks_of(hand);
-  const int p1 = __builtin_popcount(m.m1), p2 = __builtin_popcount(m.m2);
-  const int j2 = (m.m1 & JOKERS) == JOKERS;
-  int n = f.lead ? 0 : 1;  // pass: utils.py:53-55
-  if (!f.lead && f.lc == BIGBANG) return 1;  // card.py:312-313
-  n += __builtin_popcount(m.m4 & value_gate(f, QUADRIC));
-  n += j2;  // rocket beats everything below it (card.py:314-315)
-  auto want = [&](int c) { return f.lead || f.lc == c; };
-  if (want(SINGLE)) n += __builtin_popcount(m.m1 & value_gate(f, SINGLE));
-  if (want(DOUBLE)) n += __builtin_popcount(m.m2 & value_gate(f, DOUBLE));
-  if (want(TRIPLE)) n += __builtin_popcount(m.m3 & value_gate(f, TRIPLE));
-  if (want(THREE_ONE)) n += __builtin_popcount(m.m3 & value_gate(f, THREE_ONE)) * (p1 - 1);
-  if (want(THREE_TWO)) n += __builtin_popcount(m.m3 & value_gate(f, THREE_TWO)) * (p2 - 1);
-  // chains: card.py:86-105 (len 5..12 / 3..10 / 2..6 within 3..A)
-  auto chains = [&](uint32_t mask, int c, int lo, int hi) {
-    if (!want(c)) return 0;
-    uint32_t mm = mask & M12, gate = value_gate(f, c);
-    int k = 0;
-    if (f.lead) {
-      uint32_t x = run_starts(mm, lo);
-      for (int L = lo; L <= hi && x; ++L) { k += __builtin_popcount(x); x &= mm >> L; }
-    } else if (f.ll >= lo && f.ll <= hi) {
-      k = __builtin_popcount(run_starts(mm, f.ll) & gate);
-    }
-    return k;
-  };
-  n += chains(m.m1, SINGLE_LINE, 5, 12);
-  n += chains(m.m2, DOUBLE_LINE, 3, 10);
-  n += chains(m.m3, TRIPLE_LINE, 2, 6);
-  // planes with kickers: card.py:110-129
-  auto planes = [&](int c, uint32_t kick, uint32_t ranks, int hi, bool skipj) {
-    if (!want(c)) return 0;
-    uint32_t mm = m.m3 & M12, gate = value_gate(f, c);
-    int k = 0;
-    int lo = f.lead ? 2 : f.ll, up = f.lead ? hi : (f.ll <= hi ? f.ll : 0);
-    for (int L = lo; L <= up; ++L) {
-      uint32_t st = run_starts(mm, L) & gate;
-      while (st) {
-        int s = __builtin_ctz(st);
-        st &= st - 1;
-        uint32_t run = ((1u << L) - 1u) << s;
-        k += binom(__builtin_popcount(kick & ranks & ~run), L) - ((skipj && L == 2 && j2) ? 1 : 0);
-      }
-    }
-    return k;
-  };
-  n += planes(THREE_ONE_LINE, m.m1, M15, 5, true);
-  n += planes(THREE_TWO_LINE, m.m2, M13, 4, false);
-  // four with two kickers: card.py:139-153
-  if (want(FOUR_TAKE_ONE))
-    n += __builtin_popcount(m.m4 & value_gate(f, FOUR_TAKE_ONE)) * (binom(p1 - 1, 2) - j2);
-  if (want(FOUR_TAKE_TWO))
-    n += __builtin_popcount(m.m4 & value_gate(f, FOUR_TAKE_TWO)) * binom(p2 - 1, 2);
-  return n;
-}
-
 // ---- Philox4x32-10 -----------------------------------------------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll

@@ -1,18 +1,26 @@
 // ddz_engine.hip -- gfx950 kernels + C ABI (include/ddz_env.h) of the batched Doudizhu engine.
 //
 // Kernel map (reference paths relative to /root/reference):
-//   k_step    one thread per table: pick (engine RNG / index / row), apply the action
-//             (envi.py:38-43 _update + native step_manual), terminal + reward
-//             (rule_play.py:14), auto-reset deal (native prepare(), spec v1), then the
-//             closed-form size of the next legal list and a block scan of those sizes.
-//             Also serves reset (deal only) and count-only passes.
-//   k_enum    one wavefront per table: the combo enumerator + follow filter
-//             (r.get_moves, envi.py:111; rules card.py:34-159, :307-325,
-//             utils.py:45-63), structurally per category, __ballot + mbcnt compaction
-//             into the CSR row list, 16-byte coalesced row stores, canonical id order.
-//   k_query   stateless (hand,last) queries -> same records k_enum consumes (r.get_moves).
+//   k_table   ONE WAVEFRONT PER TABLE, the whole lock-step iteration in one launch:
+//             lanes 0..10 load the table's 11 packed rows (176 contiguous bytes), then
+//             [enumerate] the combo enumerator + follow filter (r.get_moves, envi.py:111;
+//                 rules utils.py:45-63 get_mask, card.py:307-325 bigger_than) as a pruned
+//                 dense scan: a scalar planner picks the id ranges of the action space
+//                 (card.py:34-159 order) that can be legal for this hand; each lane tests
+//                 one id per round against the per-action record table (SWAR nibble
+//                 subset test + follow gate), __ballot + mbcnt compaction into the CSR
+//                 row list, 16-byte coalesced row stores, ascending canonical id;
+//             [step] pick (engine RNG, captured during the scan / index / row search),
+//                 apply (envi.py:38-43 _update + native step_manual) as a lane-parallel
+//                 byte-wise update of the 11 rows, terminal + reward (rule_play.py:14),
+//                 auto-reset deal (native prepare(), spec v2: lane-parallel ranking);
+//             [count] the same scan without stores on the NEW state -> list size, block
+//                 scan of the sizes -> CSR bases of the next launch (double-buffered).
+//             Table-level control flow is wave-uniform (scalar branches, no divergence).
+//   k_moves   stateless r.get_moves(hand, last) queries, one wavefront per query.
+//   k_build_table  fills the record table once per device with the structural enumerator
+//             (rank masks -> rows/ids in closed form), itself pinned by the golden tests.
 //   k_observe the `face` tensors (envi.py:87-96,165-217), k_onehot batch_arr2onehot (:139-146).
-// No table of the action space is read: ids/rows are computed from rank masks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,46 +33,50 @@ using namespace ddz;
 
 namespace {
 
-constexpr int BLOCK = 256;  // threads per block for every kernel
-constexpr int MODE_RESET = 3, MODE_COUNT = 4;
+constexpr int BLOCK = 256;       // threads per block of the thread-per-item kernels
+constexpr int WPB = 8;           // wavefronts per block of k_table
+constexpr int TB = WPB * 64;     // threads per block of k_table
+constexpr int STATE_ROW_BYTES = DDZ_NFIELDS * DDZ_ROW;  // 176
+
+// k_table phases
+constexpr int F_ENUM = 1, F_STEP = 2, F_RESET = 4, F_COUNT = 8;
 
 // ------------------------------------------------------------------------------------
 // scratch layout (caller-owned, zero-filled at create)
 struct Layout {
   int64_t T, nblk;
-  int64_t off_q, off_counts, off_local, off_blk_tot, off_blk_stats, off_status, bytes;
+  int64_t off_counts, off_local, off_blk_tot, off_blk_stats, off_status, bytes;
 };
-__host__ __device__ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline Layout make_layout(int64_t T) {
   Layout l;
   l.T = T;
-  l.nblk = (T + BLOCK - 1) / BLOCK;
+  l.nblk = (T + 3) / 4;  // upper bound of blocks for any launch geometry (>= 4 tables per block)
   int64_t o = 0;
-  l.off_q = o;          o = align_up(o + T * 16, 256);
-  l.off_counts = o;     o = align_up(o + T * 4, 256);
-  l.off_local = o;      o = align_up(o + T * 4, 256);
-  l.off_blk_tot = o;    o = align_up(o + l.nblk * 4, 256);
+  l.off_counts = o;     o = align_up(o + 2 * T * 4, 256);          // double-buffered
+  l.off_local = o;      o = align_up(o + 2 * T * 4, 256);
+  l.off_blk_tot = o;    o = align_up(o + 2 * l.nblk * 4, 256);
   l.off_blk_stats = o;  o = align_up(o + l.nblk * 32, 256);
   l.off_status = o;     o = align_up(o + 64, 256);
   l.bytes = o;
   return l;
 }
 struct Scratch {  // device pointers into the scratch buffer
-  uint4* q;              // per table: {hand nib lo, hi, info|flags, 0}
-  int32_t* counts;       // size of each table's legal list
-  int32_t* local_off;    // exclusive scan of counts inside the table's 256-block
-  int32_t* blk_tot;      // sum of counts per 256-block
+  int32_t* counts[2];    // size of each table's legal list (ping-pong)
+  int32_t* local_off[2]; // exclusive scan of counts inside the table's block
+  int32_t* blk_tot[2];   // sum of counts per block
   int64_t* blk_stats;    // [nblk][4] plies, episodes, lord wins, -
   int32_t* status;       // [0] status bits
-  int64_t* legal_rows;   // running total of rows produced by k_enum
+  int64_t* legal_rows;   // running total of rows produced
 };
 inline Scratch bind(void* scratch, const Layout& l) {
   uint8_t* p = (uint8_t*)scratch;
   Scratch s;
-  s.q = (uint4*)(p + l.off_q);
-  s.counts = (int32_t*)(p + l.off_counts);
-  s.local_off = (int32_t*)(p + l.off_local);
-  s.blk_tot = (int32_t*)(p + l.off_blk_tot);
+  for (int k = 0; k < 2; ++k) {
+    s.counts[k] = (int32_t*)(p + l.off_counts) + k * l.T;
+    s.local_off[k] = (int32_t*)(p + l.off_local) + k * l.T;
+    s.blk_tot[k] = (int32_t*)(p + l.off_blk_tot) + k * l.nblk;
+  }
   s.blk_stats = (int64_t*)(p + l.off_blk_stats);
   s.status = (int32_t*)(p + l.off_status);
   s.legal_rows = (int64_t*)(p + l.off_status + 16);
@@ -94,6 +106,12 @@ constexpr LineLut make_line_lut() {
 }
 __constant__ LineLut c_line_lut = make_line_lut();
 
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+  return (uint64_t)rl((uint32_t)v, l) | ((uint64_t)rl((uint32_t)(v >> 32), l) << 32);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ------------------------------------------------------------------------------------
 // wave-cooperative emission: lanes holding a legal candidate append their row at
 // base + n + (number of legal lanes below), in lane order.
@@ -102,20 +120,33 @@ struct Out {
   int32_t* ids;
   int64_t base, cap;
 };
+// the row with list index `want` is captured (wave-uniform) while it is emitted
+struct Pick {
+  int want;
+  uint32_t r0, r1, r2, r3;
+};
 
-template <bool IDS>
-__device__ __forceinline__ int emit(bool legal, uint64_t nib, int cat, int id, const Out& o, int n) {
+template <bool IDS, bool PICK>
+__device__ __forceinline__ int emit(bool legal, uint64_t nib, int cat, int id, const Out& o, int n, Pick& pk) {
   const uint64_t b = __ballot(legal);
+  const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+  const uint4 row = unpack_row(nib, (uint32_t)cat);
   if (legal) {
-    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
     const int64_t pos = o.base + n + pre;
     if (pos < o.cap) {
-      o.rows[pos] = unpack_row(nib, (uint32_t)cat);
+      o.rows[pos] = row;
       if (IDS) o.ids[pos] = id;
     }
   }
-  return n + __popcll(b);
+  const int k = __popcll(b);
+  if (PICK) {
+    const int w = pk.want - n;
+    if (w >= 0 && w < k) {  // wave-uniform
+      const int src = __builtin_ctzll(__ballot(legal && pre == w));
+      pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
+    }
+  }
+  return n + k;
 }
 
 __device__ __forceinline__ int binom_sel(int a, int b) {  // a uniform, b per lane (-1..4)
@@ -127,9 +158,9 @@ __device__ __forceinline__ int binom_sel(int a, int b) {  // a uniform, b per la
 // every L-subset K of the ranks in `av`, in lexicographic order, as
 // row = mainnib + mult * K; id = idbase + lex rank of K among the L-subsets of `rm`
 // (itertools.combinations(remains, L), card.py:115,128,141,152).
-template <bool IDS>
-__device__ int emit_combos(uint32_t av, uint32_t rm, int L, uint64_t mainnib, int mult, int cat,
-                           int idbase, bool skipj, int lane, const Out& o, int n) {
+template <bool IDS, bool PICK>
+__device__ int emit_combos(uint32_t av, uint32_t rm, int L, uint64_t mainnib, int mult, int cat, int idbase,
+                           bool skipj, int lane, const Out& o, int n, Pick& pk) {
   const int m = __builtin_popcount(av);
   const int total = binom(m, L);
   for (int i0 = 0; i0 < total; i0 += 64) {
@@ -158,7 +189,7 @@ __device__ int emit_combos(uint32_t av, uint32_t rm, int L, uint64_t mainnib, in
       }
     }
     const bool legal = act && !(skipj && L == 2 && K == JOKERS);  // card.py:116, :142
-    n = emit<IDS>(legal, mainnib + (uint64_t)mult * spread15(K), cat, idbase + lex, o, n);
+    n = emit<IDS, PICK>(legal, mainnib + (uint64_t)mult * spread15(K), cat, idbase + lex, o, n, pk);
   }
   return n;
 }
@@ -166,8 +197,8 @@ __device__ int emit_combos(uint32_t av, uint32_t rm, int L, uint64_t mainnib, in
 // The enumerator for one table, executed by one wavefront.  `hand`, `info` are
 // wave-uniform.  Returns the number of rows (uniform).  Emission order == ascending
 // canonical id == index order of card.py:get_action_space().
-template <bool IDS>
-__device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int lane, const Out& o) {
+template <bool IDS, bool PICK>
+__device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;
   const Follow f = follow_of(info);
   // rank masks by ballot: lane r < 15 looks at rank r
@@ -177,7 +208,7 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
   const uint32_t m3 = (uint32_t)__ballot(cnt >= 3) & M13;
   const uint32_t m4 = (uint32_t)__ballot(cnt >= 4) & M13;
   int n = 0;
-  if (!f.lead && f.lc == BIGBANG) return emit<IDS>(lane == 0, 0, EMPTY, 0, o, n);  // card.py:312-313
+  if (!f.lead && f.lc == BIGBANG) return emit<IDS, PICK>(lane == 0, 0, EMPTY, 0, o, n, pk);  // card.py:312-313
 
   {  // ids 0..54: pass, singles, pairs, triples, bombs -- one lane each
     const int g = lane == 0 ? 0 : lane < 16 ? 1 : lane < 29 ? 2 : lane < 42 ? 3 : lane < 55 ? 4 : 5;
@@ -188,7 +219,7 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
                         : g == 4 ? (m4 & value_gate(f, QUADRIC))
                                  : 0u;
     const bool legal = g == 0 ? !f.lead : ((mk >> (r & 15)) & 1u);
-    n = emit<IDS>(legal, (uint64_t)(g & 7) << (4 * (r & 15)), g, lane, o, n);
+    n = emit<IDS, PICK>(legal, (uint64_t)(g & 7) << (4 * (r & 15)), g, lane, o, n, pk);
   }
   if (f.lead || f.lc == THREE_ONE) {  // card.py:69-73, four mains per round
     const uint32_t mains = m3 & value_gate(f, THREE_ONE);
@@ -196,8 +227,8 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
       if (((mains >> (4 * it)) & 15u) == 0) continue;
       const int q = lane / 15, k = lane - 15 * q, main = 4 * it + q;
       const bool legal = lane < 60 && main < 13 && ((mains >> main) & 1u) && k != main && ((m1 >> k) & 1u);
-      n = emit<IDS>(legal, (3ull << (4 * (main & 15))) + (1ull << (4 * k)), THREE_ONE,
-                    ID_THREE_ONE + main * 14 + (k < main ? k : k - 1), o, n);
+      n = emit<IDS, PICK>(legal, (3ull << (4 * (main & 15))) + (1ull << (4 * k)), THREE_ONE,
+                          ID_THREE_ONE + main * 14 + (k < main ? k : k - 1), o, n, pk);
     }
   }
   if (f.lead || f.lc == THREE_TWO) {  // card.py:78-82
@@ -206,8 +237,8 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
       if (((mains >> (4 * it)) & 15u) == 0) continue;
       const int q = lane / 13, k = lane - 13 * q, main = 4 * it + q;
       const bool legal = lane < 52 && main < 13 && ((mains >> main) & 1u) && k != main && ((m2 >> k) & 1u);
-      n = emit<IDS>(legal, (3ull << (4 * (main & 15))) + (2ull << (4 * k)), THREE_TWO,
-                    ID_THREE_TWO + main * 12 + (k < main ? k : k - 1), o, n);
+      n = emit<IDS, PICK>(legal, (3ull << (4 * (main & 15))) + (2ull << (4 * k)), THREE_TWO,
+                          ID_THREE_TWO + main * 12 + (k < main ? k : k - 1), o, n, pk);
     }
   }
   // chains, one slot per lane (card.py:86-105)
@@ -218,7 +249,7 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
     const uint32_t full = (1u << L) - 1u;
     const bool legal = lane < nslots && ((mm >> s) & full) == full && (f.lead || (L == f.ll && s > f.lv));
     const uint64_t nib = (((uint64_t)mult * ONES) & ((1ull << (4 * L)) - 1ull)) << (4 * s);
-    n = emit<IDS>(legal, nib, cat, idbase + lane, o, n);
+    n = emit<IDS, PICK>(legal, nib, cat, idbase + lane, o, n, pk);
   };
   chain_round(m1, 1, SINGLE_LINE, ID_SINGLE_LINE, 36, 0, 5);
   chain_round(m2, 2, DOUBLE_LINE, ID_DOUBLE_LINE, 52, 1, 3);
@@ -231,23 +262,24 @@ __device__ int enumerate_table(uint64_t hand, uint32_t info, uint32_t lut, int l
         const uint32_t run = ((1u << L) - 1u) << s;
         const int R = __builtin_popcount(ranks) - L;
         if ((m3 & run) == run && (f.lead || (L == f.ll && s > f.lv)))
-          n = emit_combos<IDS>(kick & ranks & ~run, ranks & ~run, L,
-                               ((3ull * ONES) & ((1ull << (4 * L)) - 1ull)) << (4 * s), mult, cat, idb,
-                               skipj, lane, o, n);
+          n = emit_combos<IDS, PICK>(kick & ranks & ~run, ranks & ~run, L,
+                                     ((3ull * ONES) & ((1ull << (4 * L)) - 1ull)) << (4 * s), mult, cat, idb,
+                                     skipj, lane, o, n, pk);
         idb += binom(R, L) - ((skipj && L == 2) ? 1 : 0);
       }
   };
   planes(THREE_ONE_LINE, m1, M15, 5, 1, true, ID_THREE_ONE_LINE);
   planes(THREE_TWO_LINE, m2, M13, 4, 2, false, ID_THREE_TWO_LINE);
   // rocket (card.py:134); beats everything (card.py:314-315)
-  if ((m1 & JOKERS) == JOKERS) n = emit<IDS>(lane == 0, (1ull << 52) | (1ull << 56), BIGBANG, ID_BIGBANG, o, n);
+  if ((m1 & JOKERS) == JOKERS)
+    n = emit<IDS, PICK>(lane == 0, (1ull << 52) | (1ull << 56), BIGBANG, ID_BIGBANG, o, n, pk);
   // four with two kickers (card.py:139-153)
   auto fours = [&](int cat, uint32_t kick, uint32_t ranks, int mult, bool skipj, int idbase, int per) {
     if (!(f.lead || f.lc == cat)) return;
     for (uint32_t qm = m4 & value_gate(f, cat); qm; qm &= qm - 1) {
       const int q = __builtin_ctz(qm);
-      n = emit_combos<IDS>(kick & ranks & ~(1u << q), ranks & ~(1u << q), 2, 4ull << (4 * q), mult, cat,
-                           idbase + q * per, skipj, lane, o, n);
+      n = emit_combos<IDS, PICK>(kick & ranks & ~(1u << q), ranks & ~(1u << q), 2, 4ull << (4 * q), mult, cat,
+                                 idbase + q * per, skipj, lane, o, n, pk);
     }
   };
   fours(FOUR_TAKE_ONE, m1, M15, 1, true, ID_FOUR_TAKE_ONE, 90);
@@ -260,302 +292,520 @@ __device__ __forceinline__ int wave_sum(int v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-
-// one wavefront per table (tpw consecutive tables per wave)
-template <bool IDS>
-__global__ __launch_bounds__(BLOCK) void k_enum(const uint4* __restrict__ q,
-                                                const int32_t* __restrict__ counts,
-                                                const int32_t* __restrict__ local_off,
-                                                const int32_t* __restrict__ blk_tot, int64_t T, int tpw,
-                                                int32_t* __restrict__ offsets, uint4* __restrict__ rows,
-                                                int32_t* __restrict__ ids, int64_t cap,
-                                                int32_t* __restrict__ status,
-                                                int64_t* __restrict__ legal_rows) {
-  const int lane = threadIdx.x & 63;
-  // readfirstlane: the wave index is uniform, tell the compiler so (scalar loads, s_branches)
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + wv;
-  const int64_t t0 = wave * tpw;
-  if (t0 >= T) return;
-  const uint32_t lut = c_line_lut.v[lane];
-  // CSR base of table t0: totals of the 256-blocks before it + its offset inside its block
-  const int blk = (int)(t0 / BLOCK);
-  int part = 0;
-  for (int j = lane; j < blk; j += 64) part += blk_tot[j];
-  int64_t base = (int64_t)wave_sum(part) + local_off[t0];
-  const int ntab = (int)(T - t0 < tpw ? T - t0 : tpw);
-  uint4 rec = make_uint4(0, 0, 0, 0);
-  int cnt_l = 0;
-  if (lane < ntab) {
-    rec = q[t0 + lane];
-    cnt_l = counts[t0 + lane];
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(v, d);
+    if (lane >= d) v += y;
   }
-  Out o{rows, ids, 0, cap};
-  for (int i = 0; i < ntab; ++i) {
-    const uint64_t hand = (uint64_t)__builtin_amdgcn_readlane(rec.x, i) |
-                          ((uint64_t)__builtin_amdgcn_readlane(rec.y, i) << 32);
-    const uint32_t info = __builtin_amdgcn_readlane(rec.z, i);
-    const int cnt = __builtin_amdgcn_readlane(cnt_l, i);
-    o.base = base;
-    if (lane == 0) offsets[t0 + i] = (int32_t)base;
-    const int n = enumerate_table<IDS>(hand, info, lut, lane, o);
-    if (lane == 0) {
-      int bits = (n != cnt ? 1 : 0) | (base + cnt > cap ? 2 : 0) | ((info & QF_BADLAST) ? 4 : 0);
-      if (bits) atomicOr(status, bits);
-    }
-    base += cnt;
-  }
-  if (t0 + ntab == T && lane == 0) {
-    offsets[T] = (int32_t)base;
-    *legal_rows += base;
-  }
+  return v;
 }
 
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int block_excl_scan(int v, int* total) {
-  __shared__ int wsum[BLOCK / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(x, d);
-    if (lane >= d) x += y;
-  }
-  if (lane == 63) wsum[w] = x;
+// Per-action record table, 32 B per canonical id (433 KB: L2-resident, the hot first
+// 526 ids L1-resident), filled once per device by k_build_table:
+//   g_tab[2*id]     row bytes: int8 counts[15] + category (what is stored into the CSR list)
+//   g_tab[2*id + 1] {nib lo, nib hi, value | len << 8 | category << 16, 0}
+__device__ uint4 g_tab[2 * DDZ_NUM_ACTIONS];
+__device__ uint4 g_tmp_rows[DDZ_NUM_ACTIONS];
+__device__ int32_t g_tmp_ids[DDZ_NUM_ACTIONS];
+
+// one wavefront: enumerate the full deck on lead (every action, ids 1..13526 in order)
+__global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t lut = c_line_lut.v[lane];
+  const uint64_t deck = 0x0114444444444444ull;  // 4 of 3..2, one of each joker
+  Out o{g_tmp_rows, g_tmp_ids, 0, DDZ_NUM_ACTIONS};
+  Pick pk{-1, 0, 0, 0, 0};
+  const int n = enumerate_table<true, false>(deck, mk_info(EMPTY, 0, 1), lut, lane, o, pk);
+  __threadfence();
   __syncthreads();
-  int off = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < BLOCK / 64; ++i) {
-    if (i < w) off += wsum[i];
-    tot += wsum[i];
+  if (n != DDZ_NUM_ACTIONS - 1) {
+    if (lane == 0) atomicOr(status, 8);
+    return;
   }
-  *total = tot;
-  return off + x - v;
+  for (int p = lane; p < n + 1; p += 64) {
+    uint4 row = make_uint4(0, 0, 0, 0);
+    int id = 0;
+    if (p > 0) {
+      row = g_tmp_rows[p - 1];
+      id = g_tmp_ids[p - 1];
+      if (id != p) atomicOr(status, 8);
+    }
+    const uint64_t nib = pack_row(row);
+    const uint32_t info = info_of_row(nib, (int)(row.w >> 24));
+    g_tab[2 * id] = row;
+    g_tab[2 * id + 1] = make_uint4((uint32_t)nib, (uint32_t)(nib >> 32),
+                                   ((info >> 8) & 0xFFFF) | ((info & 0xFF) << 16), 0);
+  }
 }
 
-struct StateView {
-  uint8_t* s;
-  int64_t T;
-  __device__ __forceinline__ uint4* row(int f, int64_t t) const { return (uint4*)(s + ((int64_t)f * T + t) * 16); }
-};
-
-// deal spec v1: cards k = 0..53 in rank order; card k goes to the role picked by
-// x = (u32 * remaining) >> 32 against the remaining capacities {17 up, 20 lord, 17 down}
-// (envi.py:23).  Philox counter = (gid, episode, 1<<16 | block), key = seed.
-__device__ inline void deal(uint64_t gid, uint32_t episode, uint32_t k0, uint32_t k1, uint64_t h[3]) {
-  int cap0 = 17, cap1 = 20;
-  uint64_t h0 = 0, h1 = 0, h2 = 0;
-  for (uint32_t b = 0; b < 14; ++b) {
-    const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (1u << 16) | b), k0, k1);
-    const uint32_t dr[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = 4 * (int)b + j;
-      if (k < 54) {
-        const uint32_t x = __umulhi(dr[j], (uint32_t)(54 - k));
-        const int rank = k < 52 ? k >> 2 : k - 39;
-        const uint64_t one = 1ull << (4 * rank);
-        if (x < (uint32_t)cap0) { h0 += one; --cap0; }
-        else if (x < (uint32_t)(cap0 + cap1)) { h1 += one; --cap1; }
-        else { h2 += one; }
+// One round per 64 candidate ids [id0, id0 + count): lane tests id0 + j.
+//   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
+//             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
+// WRITE = false only counts (same code path, so count == what a later WRITE pass emits).
+template <bool WRITE, bool IDS, bool PICK>
+__device__ __forceinline__ int scan_ids(int id0, int count, uint64_t hand8, const Follow& f, int lane,
+                                        const Out& o, int n, Pick& pk) {
+  constexpr uint64_t H8 = 0x8888888888888888ull;
+  for (int j0 = 0; j0 < count; j0 += 64) {
+    const int j = j0 + lane;
+    const bool in = j < count;
+    const int id = id0 + (in ? j : 0);
+    const uint4 m = g_tab[2 * id + 1];
+    uint4 row;
+    if (WRITE) row = g_tab[2 * id];
+    const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
+    const bool sub = ((hand8 - nib) & H8) == H8;
+    const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
+    const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
+                      (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
+    const bool legal = in && sub && gate;
+    const uint64_t b = __ballot(legal);
+    const int k = __popcll(b);
+    if (WRITE) {
+      const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      if (legal) {
+        const int64_t pos = o.base + n + pre;
+        if (pos < o.cap) {
+          o.rows[pos] = row;
+          if (IDS) o.ids[pos] = id;
+        }
+      }
+      if (PICK) {
+        const int w = pk.want - n;
+        if (w >= 0 && w < k) {  // wave-uniform
+          const int src = __builtin_ctzll(__ballot(legal && pre == w));
+          pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
+        }
       }
     }
+    n += k;
   }
-  h[0] = h0; h[1] = h1; h[2] = h2;
+  return n;
+}
+
+// The planner: which id ranges of the action space can hold a legal move for this hand
+// (wave-uniform, scalar); ranges are visited in ascending id order.  Everything a range
+// admits too generously is rejected per id by scan_ids, so the planner only has to be a
+// superset -- and cheap.
+template <bool WRITE, bool IDS, bool PICK>
+__device__ int plan_scan(uint64_t hand, uint32_t info, int lane, const Out& o, Pick& pk) {
+  if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
+  const Follow f = follow_of(info);
+  const uint64_t hand8 = hand | 0x8888888888888888ull;
+  const int cnt = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
+  const uint32_t m1 = (uint32_t)__ballot(cnt >= 1) & M15;
+  const uint32_t m2 = (uint32_t)__ballot(cnt >= 2) & M13;
+  const uint32_t m3 = (uint32_t)__ballot(cnt >= 3) & M13;
+  const uint32_t m4 = (uint32_t)__ballot(cnt >= 4) & M13;
+  int n = 0;
+  auto scan = [&](int id0, int count) { n = scan_ids<WRITE, IDS, PICK>(id0, count, hand8, f, lane, o, n, pk); };
+  if (!f.lead && f.lc == BIGBANG) {  // nothing beats the rocket: pass only (card.py:312-313)
+    scan(0, 1);
+    return n;
+  }
+  if (f.lead) scan(1, 54); else scan(0, 55);  // [pass,] singles, pairs, triples, bombs
+  const uint32_t above = f.lead ? M15 : gt_mask(f.lv);
+  if (f.lead || f.lc == THREE_ONE || f.lc == THREE_TWO) {  // mains m..M of card.py:69-82
+    const uint32_t mains = m3 & above;
+    if (mains) {
+      const int lo = __builtin_ctz(mains), hi = 31 - __builtin_clz(mains);
+      if (f.lead || f.lc == THREE_ONE) scan(ID_THREE_ONE + 14 * lo, 14 * (hi - lo + 1));
+      if (f.lead || f.lc == THREE_TWO) scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
+    }
+  }
+  if (f.lead) {  // chains (card.py:86-105): the three categories are contiguous ids
+    const bool a = run_starts(m1 & M12, 5) != 0, b = run_starts(m2 & M12, 3) != 0, c = run_starts(m3 & M12, 2) != 0;
+    if (a || b || c) {
+      const int lo = a ? ID_SINGLE_LINE : b ? ID_DOUBLE_LINE : ID_TRIPLE_LINE;
+      const int hi = c ? ID_THREE_ONE_LINE : b ? ID_TRIPLE_LINE : ID_DOUBLE_LINE;
+      scan(lo, hi - lo);
+    }
+  } else if (f.lc == SINGLE_LINE) {
+    scan(ID_SINGLE_LINE, 36);
+  } else if (f.lc == DOUBLE_LINE) {
+    scan(ID_DOUBLE_LINE, 52);
+  } else if (f.lc == TRIPLE_LINE) {
+    scan(ID_TRIPLE_LINE, 45);
+  }
+  // planes with kickers (card.py:110-129): one id block per (start, len), canonical order
+  auto planes = [&](int cat, int nranks, int hi, bool skipj, int idb) {
+    if (!(f.lead || f.lc == cat) || (m3 & (m3 >> 1) & M12) == 0) return;
+    for (int s = 0; s <= 10; ++s)
+      for (int L = 2; L <= hi && s + L <= 12; ++L) {
+        const uint32_t run = ((1u << L) - 1u) << s;
+        const int size = binom(nranks - L, L) - ((skipj && L == 2) ? 1 : 0);
+        if ((m3 & run) == run && (f.lead || (L == f.ll && s > f.lv))) scan(idb, size);
+        idb += size;
+      }
+  };
+  planes(THREE_ONE_LINE, 15, 5, true, ID_THREE_ONE_LINE);
+  planes(THREE_TWO_LINE, 13, 4, false, ID_THREE_TWO_LINE);
+  if ((m1 & JOKERS) == JOKERS) scan(ID_BIGBANG, 1);  // rocket (card.py:134, :314-315)
+  if (f.lead || f.lc == FOUR_TAKE_ONE)                // card.py:139-143
+    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) scan(ID_FOUR_TAKE_ONE + 90 * __builtin_ctz(qm), 90);
+  if (f.lead || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
+    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) scan(ID_FOUR_TAKE_TWO + 66 * __builtin_ctz(qm), 66);
+  return n;
+}
+
+// ------------------------------------------------------------------------------------
+// deal spec v2: card k = 0..53 (rank k/4, 52 = BJ, 53 = CJ) draws the key
+// philox(gid, episode, 1<<16 | k/4)[k%4]; cards are ranked by (key, k); ranks 0..16 go to
+// role 0 (up), 17..36 to role 1 (lord), 37..53 to role 2 (down) (envi.py:23).
+// Lane-parallel: lane k owns card k; hands fall out of three ballots.
+__device__ __forceinline__ uint64_t nib_from_cards(uint64_t b) {  // bit k = card k held
+  uint64_t x = b & 0x000FFFFFFFFFFFFFull;
+  x = x - ((x >> 1) & 0x5555555555555555ull);
+  x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+  return x | (((b >> 52) & 1ull) << 52) | (((b >> 53) & 1ull) << 56);
+}
+__device__ inline void deal_wave(uint64_t gid, uint32_t episode, uint32_t k0, uint32_t k1, int lane,
+                                 uint64_t& o0, uint64_t& o1, uint64_t& o2) {
+  const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (1u << 16) | (uint32_t)(lane >> 2)), k0, k1);
+  const int w = lane & 3;
+  const uint32_t key = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+  int pos = 0;
+  for (int j = 0; j < 54; ++j) {
+    const uint32_t kj = rl(key, j);
+    pos += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+  }
+  const bool card = lane < 54;
+  o0 = nib_from_cards(__ballot(card && pos < 17));
+  o1 = nib_from_cards(__ballot(card && pos >= 17 && pos < 37));
+  o2 = nib_from_cards(__ballot(card && pos >= 37));
 }
 
 // the combo to beat: previous player's handout, else the one before, else lead
-// (envi.py:103-109).  b1/b2 = recent rows of (role-1)%3 and (role-2)%3.
-__device__ __forceinline__ uint32_t last_info(uint4 b1, uint4 b2) {
-  const uint64_t n1 = pack_row(b1), n2 = pack_row(b2);
-  if (n1) return info_of_row(n1, (int)(b1.w >> 24));
-  if (n2) return info_of_row(n2, (int)(b2.w >> 24));
+// (envi.py:103-109).  (n1,c1)/(n2,c2) = nib + category byte of recent[(role-1)%3] / [(role-2)%3].
+__device__ __forceinline__ uint32_t last_info(uint64_t n1, int c1, uint64_t n2, int c2) {
+  if (n1) return info_of_row(n1, c1);
+  if (n2) return info_of_row(n2, c2);
   return mk_info(EMPTY, 0, 1);
 }
 
-struct StepArgs {
+// DDZ_STAMP: diagnostic build only (tools/stamp_build.sh): per-table s_memtime stamps at the
+// phase boundaries of k_table, written to a debug buffer nothing else reads.
+#ifdef DDZ_STAMP
+__device__ unsigned long long* g_stamps = nullptr;  // [T][8]
+#define STAMP(k)                                                                       \
+  do {                                                                                 \
+    if (g_stamps && lane == 0) g_stamps[8 * t + (k)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+struct TableArgs {
   uint8_t* state;
   int64_t T;
-  uint32_t k0, k1;    // philox key = seed
+  int tpw;                   // tables per wave (consecutive)
+  uint32_t k0, k1;           // philox key = seed
   uint64_t gid_base;
-  int mode, auto_reset;
+  int auto_reset;
   const void* sel;           // CHOICE: int32[T]; ROWS: int8[T][16]; RESET: u8 mask[T] or null
-  const int32_t* offsets;    // CSR of the current state
-  const uint4* rows;
-  int64_t cap;               // rows actually backed by memory
+  int32_t* offsets;          // CSR of the current state (written by F_ENUM, read by a bare F_STEP)
+  uint4* rows;
+  int32_t* ids;
+  int64_t cap;
+  const int32_t* cur_counts; // sizes / scan of the CURRENT state's lists (previous launch)
+  const int32_t* cur_local;
+  const int32_t* cur_blk;
+  int32_t* nxt_counts;       // same for the state this launch produces
+  int32_t* nxt_local;
+  int32_t* nxt_blk;
   uint8_t* done;
   int8_t* reward;
   uint8_t* illegal;
   uint4* traj;               // [T][2]
-  Scratch sc;
+  int64_t* blk_stats;
+  int32_t* status;
+  int64_t* legal_rows;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_step(StepArgs a) {
-  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const bool in = t < a.T;
-  const StateView S{a.state, a.T};
-  uint64_t qhand = 0;
-  uint32_t qinfo = QF_FROZEN;
-  int st_ply = 0, st_eps = 0, st_lord = 0;
-  if (in) {
-    uint4 meta = *S.row(DDZ_F_META, t);
-    int role = meta.x & 0xFF;
-    if (role > 2) role = 0;  // never index outside the state on a corrupted import
-    const bool was_done = (meta.x >> 8) & 0xFF, dealt = (meta.y >> 16) & 0xFF;
-    uint32_t ply = meta.y & 0xFFFF, episode = meta.z;
+template <int FLAGS, int MODE, bool IDS>
+__global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
+  constexpr bool ENUM = FLAGS & F_ENUM, STEP = FLAGS & F_STEP, RESET = FLAGS & F_RESET;
+  constexpr bool COUNT = (FLAGS & (F_STEP | F_RESET | F_COUNT)) != 0;
+  constexpr bool PICK = ENUM && STEP && MODE == DDZ_STEP_RANDOM;
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * a.tpw;
+  const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;  // wave-uniform
+  int64_t base = 0;
+  int cnt_l = 0;      // lane i: size of the current list of table t0 + i
+  int new_cnt_l = 0;  // lane i: size of the next list of table t0 + i
+  int s_ply = 0, s_eps = 0, s_lord = 0;
+  if (ENUM && ntab > 0) {
+    // CSR base of table t0: totals of the blocks before this one + offset inside the block
+    int part = 0;
+    for (int j = lane; j < (int)blockIdx.x; j += 64) part += a.cur_blk[j];
+    base = (int64_t)wave_sum(part) + a.cur_local[t0];
+    if (lane < ntab) cnt_l = a.cur_counts[t0 + lane];
+  }
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    STAMP(0);
+    uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
+    uint4 R = make_uint4(0, 0, 0, 0);
+    if (lane < DDZ_NFIELDS) R = trow[lane];
+    uint64_t P = pack_row(R);
+    const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
+    int role = mx & 0xFF;
+    if (role > 2) role = 0;  // never index outside the table on a corrupted import
+    bool is_done = (mx >> 8) & 0xFF, dealt = (my >> 16) & 0xFF;
+    uint32_t ply = my & 0xFFFF, episode = mz;
     const uint64_t gid = a.gid_base + (uint64_t)t;
-    bool redeal = false;
-    if (a.mode == MODE_RESET) {
-      const uint8_t* mask = (const uint8_t*)a.sel;
-      if (!mask || mask[t]) {
-        redeal = true;
-        episode = dealt ? episode + 1 : 0;
+    const bool active = dealt && !is_done;
+    const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+    uint64_t hand = rl64(P, DDZ_F_HAND0 + role);
+    uint32_t info = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
+                              rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+    int cnt = 0;
+    Pick pk{-1, 0, 0, 0, 0};
+    STAMP(1);
+    if (ENUM) {
+      cnt = (int)rl((uint32_t)cnt_l, i);
+      if (lane == 0) a.offsets[t] = (int32_t)base;
+      if (PICK && active && cnt > 0) {  // random.choice(actions), envi.py:83
+        const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
+        pk.want = (int)__umulhi(rfl(d.x), (uint32_t)cnt);
       }
-    } else if (a.mode != MODE_COUNT) {
-      const int32_t off = a.offsets[t];
-      int32_t A = a.offsets[t + 1] - off;
-      if (off < 0 || (int64_t)off + A > a.cap) A = 0;  // list was truncated: nothing to pick from
-      const bool frozen = was_done || !dealt || A <= 0;
-      int32_t idx = -1;
+      const Out o{a.rows, a.ids, base, a.cap};
+      const int n = plan_scan<true, IDS, PICK>(hand, active ? info : QF_FROZEN, lane, o, pk);
+      if (lane == 0) {
+        const int bits = (n != cnt ? 1 : 0) | (base + cnt > a.cap ? 2 : 0);
+        if (bits) atomicOr(a.status, bits);
+      }
+    }
+    bool changed = false;
+    STAMP(2);
+    if (STEP) {
+      int64_t off = base;
+      int A = cnt;
+      if (!ENUM) {
+        off = a.offsets[t];
+        A = a.offsets[t + 1] - (int32_t)off;
+      }
+      if (off < 0 || off + A > a.cap) A = 0;  // list was truncated: nothing to pick from
+      const bool frozen = !active || A <= 0;
+      int idx = -1;
+      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen row, wave-uniform
       if (!frozen) {
-        if (a.mode == DDZ_STEP_RANDOM) {  // random.choice(actions), envi.py:83
-          const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
-          idx = (int32_t)__umulhi(d.x, (uint32_t)A);
-        } else if (a.mode == DDZ_STEP_CHOICE) {
+        if (MODE == DDZ_STEP_RANDOM) {
+          if (PICK) {
+            idx = pk.want; c0 = pk.r0; c1 = pk.r1; c2 = pk.r2; c3 = pk.r3;
+          } else {
+            const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
+            idx = (int)__umulhi(rfl(d.x), (uint32_t)A);
+          }
+        } else if (MODE == DDZ_STEP_CHOICE) {
           idx = ((const int32_t*)a.sel)[t];
           if (idx < 0 || idx >= A) idx = -1;
-        } else {
+        } else {  // wave-parallel search of the segment for the wanted counts
           const uint4 want = ((const uint4*)a.sel)[t];
-          for (int32_t j = 0; j < A && idx < 0; ++j) {
-            const uint4 r = a.rows[off + j];
-            if (r.x == want.x && r.y == want.y && r.z == want.z && ((r.w ^ want.w) & 0x00FFFFFFu) == 0) idx = j;
+          for (int j0 = 0; j0 < A && idx < 0; j0 += 64) {
+            bool hit = false;
+            if (j0 + lane < A) {
+              const uint4 r = a.rows[off + j0 + lane];
+              hit = r.x == want.x && r.y == want.y && r.z == want.z && ((r.w ^ want.w) & 0x00FFFFFFu) == 0;
+            }
+            const uint64_t hb = __ballot(hit);
+            if (hb) idx = j0 + __builtin_ctzll(hb);
           }
+        }
+        if (idx >= 0 && !PICK) {
+          const uint4 r = a.rows[off + idx];
+          c0 = rfl(r.x); c1 = rfl(r.y); c2 = rfl(r.z); c3 = rfl(r.w);
         }
       }
       uint4 tr0 = make_uint4(0, 0, 0, 0);
       uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)A & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
-      uint8_t o_done = was_done, o_illegal = 0;
-      int8_t o_reward = 0;
+      uint32_t o_done = is_done, o_illegal = 0, o_reward = 0;
       if (frozen) {
-        tr1.x |= (uint32_t)was_done << 8 | 2u << 24;
+        tr1.x |= (uint32_t)is_done << 8 | 2u << 24;
       } else if (idx < 0) {
         o_done = 0; o_illegal = 1;
         tr1.x |= 1u << 24;
       } else {
-        const uint4 row = a.rows[off + idx];
-        const uint4 rowc = make_uint4(row.x, row.y, row.z, row.w & 0x00FFFFFFu);
-        const int ncards = nib_sum(pack_row(row));
-        uint4* ph = S.row(DDZ_F_HAND0 + role, t);
-        uint4* pi = S.row(DDZ_F_HIST0 + role, t);
-        uint4* pt = S.row(DDZ_F_TAKEN, t);
-        uint4 h = *ph, hi = *pi, tk = *pt;
-        // byte-wise: every byte of the hand >= the row's byte, so no borrows cross bytes
-        h.x -= rowc.x; h.y -= rowc.y; h.z -= rowc.z; h.w -= rowc.w + ((uint32_t)ncards << 24);
-        hi.x += rowc.x; hi.y += rowc.y; hi.z += rowc.z; hi.w += rowc.w;
-        tk.x += rowc.x; tk.y += rowc.y; tk.z += rowc.z; tk.w += rowc.w;
-        *ph = h; *pi = hi; *pt = tk;                 // envi.py:39-41
-        *S.row(DDZ_F_RECENT0 + role, t) = row;       // envi.py:43
-        const bool won = (h.w >> 24) == 0;
-        o_reward = won ? (role == 1 ? -1 : 1) : 0;   // rule_play.py:14
+        changed = true;
+        const uint32_t cw3 = c3 & 0x00FFFFFFu;
+        const uint32_t ncards = (uint32_t)nib_sum(pack_row(make_uint4(c0, c1, c2, c3)));
+        // lane-parallel update of the table's rows (envi.py:39-43); byte-wise: every byte
+        // of the hand >= the row's byte, so no borrow/carry crosses a byte
+        if (lane == DDZ_F_HAND0 + role) {
+          R.x -= c0; R.y -= c1; R.z -= c2; R.w -= cw3 + (ncards << 24);
+        } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
+          R.x += c0; R.y += c1; R.z += c2; R.w += cw3;
+        } else if (lane == DDZ_F_RECENT0 + role) {
+          R = make_uint4(c0, c1, c2, c3);
+        }
+        const bool won = (rl(R.w, DDZ_F_HAND0 + role) >> 24) == 0;
+        o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14: -1 lord won, +1 farmers
         o_done = won;
-        st_ply = 1; st_eps = won; st_lord = won && role == 1;
-        tr0 = row;
-        tr1.x |= (uint32_t)won << 8 | ((uint32_t)(uint8_t)o_reward) << 16;
+        s_ply += 1; s_eps += won; s_lord += (won && role == 1);
+        tr0 = make_uint4(c0, c1, c2, c3);
+        tr1.x |= (uint32_t)won << 8 | o_reward << 16;
         tr1.w = (uint32_t)idx;
-        const int nrole = role == 2 ? 0 : role + 1;  // lord -> down -> up, game.py:173-181
+        const int nrole = rp1;  // lord -> down -> up, game.py:173-181
         ply += 1;
         if (won && a.auto_reset) {
-          redeal = true;
           episode += 1;
+          uint64_t h0, h1, h2;
+          deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
+          R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+              : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
+          role = 1; is_done = false;
         } else {
-          meta.x = (uint32_t)nrole | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) |
-                   ((uint32_t)(uint8_t)o_reward << 24);
-          meta.y = (meta.y & 0xFFFF0000u) | (ply & 0xFFFF);
-          *S.row(DDZ_F_META, t) = meta;
-          if (!won) {  // query of the next actor: its hand + the two most recent handouts
-            const uint4 nh = *S.row(DDZ_F_HAND0 + nrole, t);
-            const uint4 b2 = *S.row(DDZ_F_RECENT0 + (role == 0 ? 2 : role - 1), t);
-            qhand = pack_row(nh);
-            qinfo = last_info(row, b2);
-          }
+          if (lane == DDZ_F_META)
+            R = make_uint4((uint32_t)nrole | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) | (o_reward << 24),
+                           (my & 0xFFFF0000u) | (ply & 0xFFFF), mz, R.w);
+          role = nrole; is_done = won;
         }
       }
-      if (a.done) a.done[t] = o_done;
-      if (a.reward) a.reward[t] = o_reward;
-      if (a.illegal) a.illegal[t] = o_illegal;
-      if (a.traj) { a.traj[2 * t] = tr0; a.traj[2 * t + 1] = tr1; }
-      if (frozen || idx < 0) {  // state unchanged: recount it below as MODE_COUNT does
-        if (!was_done && dealt) {
-          const uint4 nh = *S.row(DDZ_F_HAND0 + role, t);
-          qhand = pack_row(nh);
-          qinfo = last_info(*S.row(DDZ_F_RECENT0 + (role + 2) % 3, t), *S.row(DDZ_F_RECENT0 + (role + 1) % 3, t));
-        }
+      if (lane == 0) {
+        if (a.done) a.done[t] = (uint8_t)o_done;
+        if (a.reward) a.reward[t] = (int8_t)o_reward;
+        if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
+      }
+      if (a.traj && lane < 2) a.traj[2 * t + lane] = lane == 0 ? tr0 : tr1;
+    }
+    STAMP(3);
+    if (RESET) {
+      const uint8_t* mask = (const uint8_t*)a.sel;
+      if (!mask || mask[t]) {
+        changed = true;
+        episode = dealt ? episode + 1 : 0;
+        uint64_t h0, h1, h2;
+        deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
+        R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+            : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
+        role = 1; is_done = false; dealt = true;
       }
     }
-    if (redeal) {
-      uint64_t h[3];
-      deal(gid, episode, a.k0, a.k1, h);
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      *S.row(DDZ_F_HAND0 + 0, t) = unpack_row(h[0], 17);
-      *S.row(DDZ_F_HAND0 + 1, t) = unpack_row(h[1], 20);
-      *S.row(DDZ_F_HAND0 + 2, t) = unpack_row(h[2], 17);
+    if (changed) {
+      if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
+      if (COUNT) {                             // query of the new actor
+        P = pack_row(R);
+        const int q1 = role == 0 ? 2 : role - 1, q2 = role == 2 ? 0 : role + 1;
+        hand = rl64(P, DDZ_F_HAND0 + role);
+        info = last_info(rl64(P, DDZ_F_RECENT0 + q1), (int)(rl(R.w, DDZ_F_RECENT0 + q1) >> 24),
+                         rl64(P, DDZ_F_RECENT0 + q2), (int)(rl(R.w, DDZ_F_RECENT0 + q2) >> 24));
+      }
+    }
+    STAMP(4);
+    if (COUNT) {
+      const Out none{nullptr, nullptr, 0, 0};
+      Pick nopk{-1, 0, 0, 0, 0};
+      const int c = (dealt && !is_done) ? plan_scan<false, false, false>(hand, info, lane, none, nopk) : 0;
+      if (lane == i) new_cnt_l = c;
+    }
+    STAMP(5);
+    base += cnt;
+  }
+  if (ENUM && ntab > 0 && t0 + ntab == a.T && lane == 0) {
+    a.offsets[a.T] = (int32_t)base;
+    *a.legal_rows += base;
+  }
+  if (COUNT) {
+    __shared__ int sh[WPB][4];
+    const int incl = wave_incl_scan(new_cnt_l, lane);
+    if (lane == 63) {
+      sh[wv][0] = incl; sh[wv][1] = s_ply; sh[wv][2] = s_eps; sh[wv][3] = s_lord;
+    }
+    __syncthreads();
+    int wbase = 0, tot = 0;
 #pragma unroll
-      for (int f = DDZ_F_HIST0; f <= DDZ_F_TAKEN; ++f) *S.row(f, t) = z;  // envi.py:32-35
-      *S.row(DDZ_F_META, t) = make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0);
-      qhand = h[1];  // lord leads (game.py:173)
-      qinfo = mk_info(EMPTY, 0, 1);
-    } else if (a.mode == MODE_COUNT || a.mode == MODE_RESET) {
-      if (!was_done && dealt) {
-        qhand = pack_row(*S.row(DDZ_F_HAND0 + role, t));
-        qinfo = last_info(*S.row(DDZ_F_RECENT0 + (role + 2) % 3, t), *S.row(DDZ_F_RECENT0 + (role + 1) % 3, t));
+    for (int w = 0; w < WPB; ++w) {
+      if (w < wv) wbase += sh[w][0];
+      tot += sh[w][0];
+    }
+    if (lane < ntab) {
+      a.nxt_counts[t0 + lane] = new_cnt_l;
+      a.nxt_local[t0 + lane] = wbase + incl - new_cnt_l;
+    }
+#ifdef DDZ_STAMP
+    if (g_stamps && lane == 0 && ntab > 0) g_stamps[8 * t0 + 6] = __builtin_amdgcn_s_memtime();
+#endif
+    if (threadIdx.x == 0) {
+      a.nxt_blk[blockIdx.x] = tot;
+      if (STEP) {
+        int64_t* bs = a.blk_stats + 4 * (int64_t)blockIdx.x;
+        int p = 0, e = 0, l = 0;
+        for (int w = 0; w < WPB; ++w) { p += sh[w][1]; e += sh[w][2]; l += sh[w][3]; }
+        bs[0] += p; bs[1] += e; bs[2] += l;
       }
     }
-  }
-  const int cnt = (in && !(qinfo & QF_FROZEN)) ? count_legal(qhand, qinfo) : 0;
-  int total;
-  const int loff = block_excl_scan(cnt, &total);
-  if (in) {
-    a.sc.q[t] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, 0);
-    a.sc.counts[t] = cnt;
-    a.sc.local_off[t] = loff;
-  }
-  // per-block statistics (no atomics: each block owns its slot)
-  const uint64_t bp = __ballot(st_ply), be = __ballot(st_eps), bl = __ballot(st_lord);
-  __shared__ int sst[BLOCK / 64][3];
-  if ((threadIdx.x & 63) == 0) {
-    sst[threadIdx.x >> 6][0] = __popcll(bp);
-    sst[threadIdx.x >> 6][1] = __popcll(be);
-    sst[threadIdx.x >> 6][2] = __popcll(bl);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a.sc.blk_tot[blockIdx.x] = total;
-    int64_t* bs = a.sc.blk_stats + 4 * (int64_t)blockIdx.x;
-    for (int k = 0; k < 3; ++k) bs[k] += sst[0][k] + sst[1][k] + sst[2][k] + sst[3][k];
   }
 }
 
-// stateless queries: r.get_moves(hand15, last15) for n independent (hand, last) pairs
-__global__ __launch_bounds__(BLOCK) void k_query(const uint4* __restrict__ hands,
-                                                 const uint4* __restrict__ lasts, int64_t n, Scratch sc) {
-  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  uint64_t qhand = 0;
-  uint32_t qinfo = QF_FROZEN;
-  if (t < n) {
-    qhand = pack_row(hands[t]);
-    qinfo = classify(pack_row(lasts[t]));
-    if (qinfo == INFO_INVALID) qinfo = QF_BADLAST | QF_FROZEN;
-    if (ge_mask(qhand, 5) || (qhand >> 60)) qinfo = QF_BADLAST | QF_FROZEN;
+// ------------------------------------------------------------------------------------
+// stateless path: r.get_moves(hand15, last15) for n independent (hand, last) pairs, one
+// wavefront per query (tpw consecutive queries per wave); pass 1 (WRITE = false) sizes the
+// lists and scans them per block, pass 2 writes the CSR list.
+constexpr int MW = BLOCK / 64;  // waves per block of k_moves
+
+template <bool WRITE, bool IDS>
+__global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands, const uint4* __restrict__ lasts,
+                                                 int64_t n, int tpw, int32_t* __restrict__ counts,
+                                                 int32_t* __restrict__ local_off, int32_t* __restrict__ blk_tot,
+                                                 int32_t* __restrict__ offsets, uint4* __restrict__ rows,
+                                                 int32_t* __restrict__ ids, int64_t cap, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * MW + wv) * tpw;
+  const int ntab = t0 < n ? (int)(n - t0 < tpw ? n - t0 : tpw) : 0;
+  int64_t base = 0;
+  int cnt_l = 0, new_cnt_l = 0;
+  if (WRITE && ntab > 0) {
+    int part = 0;
+    for (int j = lane; j < (int)blockIdx.x; j += 64) part += blk_tot[j];
+    base = (int64_t)wave_sum(part) + local_off[t0];
+    if (lane < ntab) cnt_l = counts[t0 + lane];
   }
-  const int cnt = (t < n && !(qinfo & QF_FROZEN)) ? count_legal(qhand, qinfo) : 0;
-  int total;
-  const int loff = block_excl_scan(cnt, &total);
-  if (t < n) {
-    sc.q[t] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, 0);
-    sc.counts[t] = cnt;
-    sc.local_off[t] = loff;
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    const uint4 hr = hands[t], lr = lasts[t];
+    const uint64_t hand = pack_row(make_uint4(rfl(hr.x), rfl(hr.y), rfl(hr.z), rfl(hr.w)));
+    uint32_t info = classify(pack_row(make_uint4(rfl(lr.x), rfl(lr.y), rfl(lr.z), rfl(lr.w))));
+    if (info == INFO_INVALID || ge_mask(hand, 5) || (hand >> 60)) info = QF_BADLAST | QF_FROZEN;
+    Pick pk{-1, 0, 0, 0, 0};
+    if (WRITE) {
+      const int cnt = (int)rl((uint32_t)cnt_l, i);
+      if (lane == 0) offsets[t] = (int32_t)base;
+      const Out o{rows, ids, base, cap};
+      const int m = plan_scan<true, IDS, false>(hand, info, lane, o, pk);
+      if (lane == 0) {
+        const int bits = (m != cnt ? 1 : 0) | (base + cnt > cap ? 2 : 0) | ((info & QF_BADLAST) ? 4 : 0);
+        if (bits) atomicOr(status, bits);
+      }
+      base += cnt;
+    } else {
+      const Out none{nullptr, nullptr, 0, 0};
+      const int c = plan_scan<false, false, false>(hand, info, lane, none, pk);
+      if (lane == i) new_cnt_l = c;
+    }
   }
-  if (threadIdx.x == 0) sc.blk_tot[blockIdx.x] = total;
+  if (WRITE) {
+    if (ntab > 0 && t0 + ntab == n && lane == 0) offsets[n] = (int32_t)base;
+  } else {
+    __shared__ int sh[MW];
+    const int incl = wave_incl_scan(new_cnt_l, lane);
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+      if (w < wv) wbase += sh[w];
+      tot += sh[w];
+    }
+    if (lane < ntab) {
+      counts[t0 + lane] = new_cnt_l;
+      local_off[t0 + lane] = wbase + incl - new_cnt_l;
+    }
+    if (threadIdx.x == 0) blk_tot[blockIdx.x] = tot;
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ rows, int64_t n,
@@ -604,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(const uint8_t* __restrict__ s
   if (idx >= T * P * 15) return;
   const int64_t t = idx / (P * 15);
   const int rem = (int)(idx - t * (P * 15)), p = rem / 15, i = rem - p * 15;
-  auto byte = [&](int f, int k) { return (int)state[((int64_t)f * T + t) * 16 + k]; };
+  auto byte = [&](int f, int k) { return (int)state[t * STATE_ROW_BYTES + f * 16 + k]; };
   int role = byte(DDZ_F_META, 0);
   if (role > 2) role = 0;
   const int kind = c_face_kind[variant][p];
@@ -660,28 +910,58 @@ inline int check_launch() {
   return e == hipSuccess ? DDZ_OK : hip_fail(e);
 }
 
-inline int pick_tpw(int64_t T) {
-  if (const char* s = getenv("DDZ_TPW")) {
+inline int env_int(const char* name, int lo, int hi, int dflt) {
+  if (const char* s = getenv(name)) {
     int v = atoi(s);
-    if (v >= 1 && v <= 64) return v;
+    if (v >= lo && v <= hi) return v;
   }
-  int64_t v = (T + 16383) / 16384;
-  return (int)(v < 1 ? 1 : v > 16 ? 16 : v);
+  return dflt;
+}
+// tables per wave: one table per wave until the chip is full (256 CUs x 16 waves), then
+// consecutive tables share a wave so that the per-wave CSR prefix stays short
+inline int pick_tpw(int64_t T) {
+  int64_t v = (T + 4095) / 4096;
+  return env_int("DDZ_TPW", 1, 64, (int)(v < 1 ? 1 : v > 32 ? 32 : v));
 }
 
-int launch_enum(const Scratch& sc, int64_t T, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap,
-                hipStream_t st) {
-  if (T == 0) return DDZ_OK;
-  const int tpw = pick_tpw(T);
-  const int64_t waves = (T + tpw - 1) / tpw;
-  const dim3 grid((unsigned)((waves + BLOCK / 64 - 1) / (BLOCK / 64)));
+int launch_moves(const Scratch& sc, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* offsets,
+                 int8_t* rows, int32_t* ids, int64_t cap, hipStream_t st) {
+  int64_t v = (n + 16383) / 16384;
+  const int tpw = (int)(v < 1 ? 1 : v > 16 ? 16 : v);
+  const int64_t per_block = (int64_t)MW * tpw;
+  const dim3 grid((unsigned)((n + per_block - 1) / per_block)), block(BLOCK);
+  hipLaunchKernelGGL((k_moves<false, false>), grid, block, 0, st, (const uint4*)hands, (const uint4*)lasts, n, tpw,
+                     sc.counts[0], sc.local_off[0], sc.blk_tot[0], offsets, (uint4*)rows, ids, cap, sc.status);
+  int rc = check_launch();
+  if (rc) return rc;
   if (ids)
-    hipLaunchKernelGGL(k_enum<true>, grid, dim3(BLOCK), 0, st, sc.q, sc.counts, sc.local_off, sc.blk_tot, T, tpw,
-                       offsets, (uint4*)rows, ids, cap, sc.status, sc.legal_rows);
+    hipLaunchKernelGGL((k_moves<true, true>), grid, block, 0, st, (const uint4*)hands, (const uint4*)lasts, n, tpw,
+                       sc.counts[0], sc.local_off[0], sc.blk_tot[0], offsets, (uint4*)rows, ids, cap, sc.status);
   else
-    hipLaunchKernelGGL(k_enum<false>, grid, dim3(BLOCK), 0, st, sc.q, sc.counts, sc.local_off, sc.blk_tot, T, tpw,
-                       offsets, (uint4*)rows, (int32_t*)nullptr, cap, sc.status, sc.legal_rows);
+    hipLaunchKernelGGL((k_moves<true, false>), grid, block, 0, st, (const uint4*)hands, (const uint4*)lasts, n, tpw,
+                       sc.counts[0], sc.local_off[0], sc.blk_tot[0], offsets, (uint4*)rows, ids, cap, sc.status);
   return check_launch();
+}
+
+// the record table is built once per device, on the null stream, the first time a handle
+// (or a stateless call) needs it; this is the only place the library synchronises by itself
+constexpr int MAX_DEVICES = 64;
+bool g_table_ready[MAX_DEVICES] = {};
+int ensure_table(int device) {
+  if (device < 0 || device >= MAX_DEVICES) return DDZ_ENODEV;
+  if (g_table_ready[device]) return DDZ_OK;
+  int32_t* flag = nullptr;
+  hipError_t r = hipHostMalloc((void**)&flag, sizeof(int32_t), 0);  // host-pinned status word
+  if (r != hipSuccess) return hip_fail(r);
+  *flag = 0;
+  hipLaunchKernelGGL(k_build_table, dim3(1), dim3(64), 0, (hipStream_t)0, flag);
+  int rc = check_launch();
+  r = hipStreamSynchronize((hipStream_t)0);
+  if (rc == DDZ_OK && r != hipSuccess) rc = hip_fail(r);
+  if (rc == DDZ_OK && *flag != 0) rc = DDZ_EHIP;
+  (void)hipHostFree(flag);
+  if (rc == DDZ_OK) g_table_ready[device] = true;
+  return rc;
 }
 
 }  // namespace
@@ -695,6 +975,9 @@ struct ddz_env {
   void* scratch;
   Layout lay;
   Scratch sc;
+  int tpw;            // launch geometry of k_table (fixed per handle: the scan buffers depend on it)
+  int64_t nblocks;
+  int parity;         // which scan buffer describes the current state
   bool counts_valid;
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
 };
@@ -702,18 +985,47 @@ struct ddz_env {
 namespace {
 inline bool good(const ddz_env* e) { return e && e->magic == MAGIC; }
 
-int launch_step(ddz_env* e, int mode, const void* sel, const int32_t* offsets, const int8_t* rows, int auto_reset,
-                uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, hipStream_t st) {
-  StepArgs a;
-  a.state = e->state; a.T = e->T;
-  a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32);
-  a.gid_base = e->gid_base; a.mode = mode; a.auto_reset = auto_reset; a.sel = sel;
-  a.offsets = offsets; a.rows = (const uint4*)rows; a.cap = e->legal_cap; a.done = done; a.reward = reward; a.illegal = illegal;
-  a.traj = (uint4*)traj; a.sc = e->sc;
-  hipLaunchKernelGGL(k_step, dim3((unsigned)e->lay.nblk), dim3(BLOCK), 0, st, a);
+struct Io {  // optional buffers of one k_table launch
+  const void* sel = nullptr;
+  int32_t* offsets = nullptr;
+  int8_t* rows = nullptr;
+  int32_t* ids = nullptr;
+  int64_t cap = 0;
+  int auto_reset = 0;
+  uint8_t* done = nullptr;
+  int8_t* reward = nullptr;
+  uint8_t* illegal = nullptr;
+  uint8_t* traj = nullptr;
+};
+
+template <int FLAGS, int MODE>
+int launch_table(ddz_env* e, const Io& io, hipStream_t st) {
+  TableArgs a;
+  a.state = e->state; a.T = e->T; a.tpw = e->tpw;
+  a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
+  a.auto_reset = io.auto_reset; a.sel = io.sel;
+  a.offsets = io.offsets; a.rows = (uint4*)io.rows; a.ids = io.ids; a.cap = io.cap;
+  const int cur = e->parity, nxt = cur ^ 1;
+  a.cur_counts = e->sc.counts[cur]; a.cur_local = e->sc.local_off[cur]; a.cur_blk = e->sc.blk_tot[cur];
+  a.nxt_counts = e->sc.counts[nxt]; a.nxt_local = e->sc.local_off[nxt]; a.nxt_blk = e->sc.blk_tot[nxt];
+  a.done = io.done; a.reward = io.reward; a.illegal = io.illegal; a.traj = (uint4*)io.traj;
+  a.blk_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
+  const dim3 grid((unsigned)e->nblocks), block(TB);
+  if ((FLAGS & F_ENUM) && io.ids)
+    hipLaunchKernelGGL((k_table<FLAGS, MODE, true>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((k_table<FLAGS, MODE, false>), grid, block, 0, st, a);
   int rc = check_launch();
-  if (rc == DDZ_OK) e->counts_valid = true;
+  if (rc == DDZ_OK && (FLAGS & (F_STEP | F_RESET | F_COUNT))) {
+    e->parity = nxt;
+    e->counts_valid = true;
+  }
   return rc;
+}
+
+int ensure_counts(ddz_env* e, hipStream_t st) {
+  if (e->counts_valid) return DDZ_OK;
+  return launch_table<F_COUNT, 0>(e, Io{}, st);
 }
 }  // namespace
 
@@ -750,11 +1062,20 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   if (((uintptr_t)state | (uintptr_t)scratch) & 15) return DDZ_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DDZ_ENODEV;
+  {
+    DeviceGuard g(device);
+    if (!g.ok) return DDZ_ENODEV;
+    int rc = ensure_table(device);
+    if (rc) return rc;
+  }
   ddz_env* e = (ddz_env*)calloc(1, sizeof(ddz_env));
   if (!e) return DDZ_EINVAL;
   e->magic = MAGIC; e->T = T; e->seed = seed; e->gid_base = gid_base; e->device = device;
   e->state = (uint8_t*)state; e->scratch = scratch;
-  e->lay = make_layout(T); e->sc = bind(scratch, e->lay); e->counts_valid = false; e->legal_cap = 0;
+  e->lay = make_layout(T); e->sc = bind(scratch, e->lay);
+  e->tpw = pick_tpw(T);
+  e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
+  e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   *out = e;
   return DDZ_OK;
 }
@@ -776,7 +1097,9 @@ int ddz_reset(ddz_env_t* e, const uint8_t* mask, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  return launch_step(e, MODE_RESET, mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  Io io;
+  io.sel = mask;
+  return launch_table<F_RESET, 0>(e, io, (hipStream_t)stream);
 }
 
 int ddz_legal(ddz_env_t* e, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap, void* stream) {
@@ -785,12 +1108,12 @@ int ddz_legal(ddz_env_t* e, int32_t* offsets, int8_t* rows, int32_t* ids, int64_
   if (cap > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  if (!e->counts_valid) {
-    int rc = launch_step(e, MODE_COUNT, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
-    if (rc) return rc;
-  }
+  int rc = ensure_counts(e, (hipStream_t)stream);
+  if (rc) return rc;
   e->legal_cap = cap;
-  return launch_enum(e->sc, e->T, offsets, rows, ids, cap, (hipStream_t)stream);
+  Io io;
+  io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap;
+  return launch_table<F_ENUM, 0>(e, io, (hipStream_t)stream);
 }
 
 int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, const int8_t* rows, int auto_reset,
@@ -800,7 +1123,15 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  return launch_step(e, mode, sel, offsets, rows, auto_reset ? 1 : 0, done, reward, illegal, traj, (hipStream_t)stream);
+  Io io;
+  io.sel = sel; io.offsets = (int32_t*)offsets; io.rows = (int8_t*)rows; io.cap = e->legal_cap;
+  io.auto_reset = auto_reset ? 1 : 0; io.done = done; io.reward = reward; io.illegal = illegal; io.traj = traj;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case DDZ_STEP_RANDOM: return launch_table<F_STEP, DDZ_STEP_RANDOM>(e, io, st);
+    case DDZ_STEP_CHOICE: return launch_table<F_STEP, DDZ_STEP_CHOICE>(e, io, st);
+    default: return launch_table<F_STEP, DDZ_STEP_ROWS>(e, io, st);
+  }
 }
 
 int ddz_observe(ddz_env_t* e, int variant, float* face, void* stream) {
@@ -834,12 +1165,9 @@ int ddz_get_moves(int device, const int8_t* hands, const int8_t* lasts, int64_t 
   if (scratch_bytes < l.bytes || ((uintptr_t)scratch & 15)) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
-  const Scratch sc = bind(scratch, l);
-  hipLaunchKernelGGL(k_query, dim3((unsigned)l.nblk), dim3(BLOCK), 0, (hipStream_t)stream, (const uint4*)hands,
-                     (const uint4*)lasts, n, sc);
-  int rc = check_launch();
+  int rc = ensure_table(device);
   if (rc) return rc;
-  return launch_enum(sc, n, offsets, rows, ids, cap, (hipStream_t)stream);
+  return launch_moves(bind(scratch, l), hands, lasts, n, offsets, rows, ids, cap, (hipStream_t)stream);
 }
 
 int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {
@@ -847,7 +1175,7 @@ int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {
   if (!stats) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, e->sc, e->lay.nblk, stats);
+  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, e->sc, e->nblocks, stats);
   return check_launch();
 }
 
@@ -860,19 +1188,17 @@ int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8_t* 
   if (!g.ok) return DDZ_ENODEV;
   hipStream_t st = (hipStream_t)stream;
   e->legal_cap = cap;
+  Io io;
+  io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap; io.auto_reset = 1;
   for (int64_t it = 0; it < n_iters; ++it) {
-    if (!e->counts_valid) {
-      int rc = launch_step(e, MODE_COUNT, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
-      if (rc) return rc;
-    }
-    int rc = launch_enum(e->sc, e->T, offsets, rows, ids, cap, st);
+    int rc = ensure_counts(e, st);
     if (rc) return rc;
-    rc = launch_step(e, DDZ_STEP_RANDOM, nullptr, offsets, rows, 1, nullptr, nullptr, nullptr,
-                     traj ? traj + it * e->T * DDZ_TRAJ_BYTES : nullptr, st);
+    io.traj = traj ? traj + it * e->T * DDZ_TRAJ_BYTES : nullptr;
+    rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);  // one launch per lock-step iteration
     if (rc) return rc;
   }
   if (stats) {
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, st, e->sc, e->lay.nblk, stats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, st, e->sc, e->nblocks, stats);
     return check_launch();
   }
   return DDZ_OK;
@@ -887,37 +1213,33 @@ int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* offsets, in
   if (!g.ok) return DDZ_ENODEV;
   hipStream_t st = (hipStream_t)stream;
   e->legal_cap = cap;
-  if (!e->counts_valid) {
-    int rc = launch_step(e, MODE_COUNT, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
-    if (rc) return rc;
-  }
-  const int64_t nev = 2 * n_iters + 1;
+  int rc = ensure_counts(e, st);
+  if (rc) return rc;
+  const int64_t nev = n_iters + 1;
   hipEvent_t* ev = (hipEvent_t*)calloc((size_t)nev, sizeof(hipEvent_t));
   if (!ev) return DDZ_EINVAL;
-  int rc = DDZ_OK;
   int64_t made = 0;
   for (; made < nev; ++made)
     if (hipEventCreate(&ev[made]) != hipSuccess) { rc = hip_fail(hipGetLastError()); break; }
   if (rc == DDZ_OK) {
+    Io io;
+    io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap; io.auto_reset = 1;
     (void)hipEventRecord(ev[0], st);
     for (int64_t it = 0; it < n_iters && rc == DDZ_OK; ++it) {
-      rc = launch_enum(e->sc, e->T, offsets, rows, ids, cap, st);
-      (void)hipEventRecord(ev[2 * it + 1], st);
-      if (rc == DDZ_OK)
-        rc = launch_step(e, DDZ_STEP_RANDOM, nullptr, offsets, rows, 1, nullptr, nullptr, nullptr, nullptr, st);
-      (void)hipEventRecord(ev[2 * it + 2], st);
+      rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);
+      (void)hipEventRecord(ev[it + 1], st);
     }
     hipError_t r = hipStreamSynchronize(st);
     if (r != hipSuccess) rc = hip_fail(r);
     if (rc == DDZ_OK) {
-      double a = 0, b = 0;
+      double tot = 0;
       for (int64_t it = 0; it < n_iters; ++it) {
-        float x = 0, y = 0;
-        (void)hipEventElapsedTime(&x, ev[2 * it], ev[2 * it + 1]);
-        (void)hipEventElapsedTime(&y, ev[2 * it + 1], ev[2 * it + 2]);
-        a += x; b += y;
+        float x = 0;
+        (void)hipEventElapsedTime(&x, ev[it], ev[it + 1]);
+        tot += x;
       }
-      ms[0] = a; ms[1] = b;
+      ms[0] = tot;
+      ms[1] = 0;
     }
   }
   for (int64_t i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
@@ -935,6 +1257,12 @@ int ddz_status(ddz_env_t* e, int32_t* out, void* stream) {
   r = hipStreamSynchronize((hipStream_t)stream);
   return r == hipSuccess ? DDZ_OK : hip_fail(r);
 }
+
+#ifdef DDZ_STAMP
+int ddz_debug_set_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : DDZ_EHIP;
+}
+#endif
 
 // debug/test entry: classify(rows) -> info words (category | value << 8 | len << 16, 0xFF invalid)
 int ddz_debug_classify(int device, const int8_t* rows, int64_t n, uint32_t* out, void* stream) {

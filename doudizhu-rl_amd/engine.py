@@ -87,14 +87,14 @@ class BatchedEnv:
 
     # ---- views of the packed state ([T,16] int8/uint8, zero-copy) ----
     def field(self, f):
-        return self.state.view(NFIELDS, self.T, ROW)[f]
+        return self.state.view(self.T, NFIELDS, ROW)[:, f]
 
     @property
     def role(self):
         return self.field(F_META)[:, 0]
 
     def hands(self):
-        return self.state.view(NFIELDS, self.T, ROW)[F_HAND0:F_HAND0 + 3]
+        return self.state.view(self.T, NFIELDS, ROW)[:, F_HAND0:F_HAND0 + 3]
 
     # ---- verbs ----
     def reset(self, mask=None):

@@ -245,24 +245,27 @@ void ddzo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 
 /* ---- state helpers ------------------------------------------------------ */
 static inline uint8_t* fld(uint8_t* s, int64_t T, int f, int64_t t) {
-  return s + ((int64_t)f * T + t) * DDZO_ROW;
+  (void)T;
+  return s + (t * DDZO_NFIELDS + f) * DDZO_ROW;
 }
 static inline const uint8_t* cfld(const uint8_t* s, int64_t T, int f, int64_t t) {
-  return s + ((int64_t)f * T + t) * DDZO_ROW;
+  (void)T;
+  return s + (t * DDZO_NFIELDS + f) * DDZO_ROW;
 }
 static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline void wr32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
 static inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 static inline void wr16(uint8_t* p, uint16_t v) { memcpy(p, &v, 2); }
 
-/* deal spec v1 (the reference's shuffle lives in the absent native `env`,
- * envi.py:10-13 / game.py:171 prepare()): cards k = 0..53 in fixed order
- * (rank k/4 for k < 52, 13 = BJ, 14 = CJ); card k goes to the role chosen by
- * x = (u32 draw * remaining) >> 32 against the remaining capacities
- * {17 up, 20 lord, 17 down} (envi.py:23 left = [17, 20, 17]).               */
+/* deal spec v2 (the reference's shuffle lives in the absent native `env`,
+ * envi.py:10-13 / game.py:171 prepare()): card k = 0..53 (rank k/4 for
+ * k < 52, 13 = BJ, 14 = CJ) draws the 32-bit key philox(gid, episode,
+ * 1<<16 | k/4)[k%4]; the cards are ranked by (key, k) and the 17 smallest
+ * go to role 0 (up), the next 20 to role 1 (lord), the last 17 to role 2
+ * (down) (envi.py:23 left = [17, 20, 17]): a uniform random deal, and a
+ * lane-parallel one on the GPU.                                             */
 static void deal(uint8_t* s, int64_t T, int64_t t, uint64_t seed, uint64_t gid, uint32_t episode) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  int cap[3] = {17, 20, 17};
   uint8_t h[3][DDZO_ROW];
   memset(h, 0, sizeof h);
   uint32_t draws[56];
@@ -271,11 +274,11 @@ static void deal(uint8_t* s, int64_t T, int64_t t, uint64_t seed, uint64_t gid, 
     ddzo_philox4x32_10(ctr, key, draws + 4 * b);
   }
   for (int k = 0; k < 54; ++k) {
-    uint32_t rem = 54 - k;
-    uint32_t x = (uint32_t)(((uint64_t)draws[k] * rem) >> 32);
-    int role = x < (uint32_t)cap[0] ? 0 : x < (uint32_t)(cap[0] + cap[1]) ? 1 : 2;
+    int pos = 0;
+    for (int j = 0; j < 54; ++j)
+      pos += draws[j] < draws[k] || (draws[j] == draws[k] && j < k);
+    int role = pos < 17 ? 0 : pos < 37 ? 1 : 2;
     int rank = k < 52 ? k / 4 : k - 39;
-    --cap[role];
     ++h[role][rank];
   }
   h[0][15] = 17; h[1][15] = 20; h[2][15] = 17;

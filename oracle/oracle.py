@@ -117,7 +117,7 @@ class OracleEnv:
         self.total = 0
 
     def field(self, f):
-        return self.state.reshape(NFIELDS, self.T, ROW)[f]
+        return self.state.reshape(self.T, NFIELDS, ROW)[:, f]
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

@@ -232,7 +232,7 @@ def test_full_size_properties(pkg, T):
     assert s["plies"] == T * iters
     assert 0.8 * T * iters / 66 < s["episodes"] < 1.25 * T * iters / 60   # ~65 plies per episode
     assert 0 < s["lord_wins"] < s["episodes"]
-    st = env.state.view(11, T, 16).cpu().numpy().astype(np.int64)
+    st = env.state.view(T, 11, 16).permute(1, 0, 2).cpu().numpy().astype(np.int64)
     deck = np.array([4] * 13 + [1, 1])
     hands = st[0:3, :, :15]
     assert np.array_equal(hands.sum(0) + st[9, :, :15], np.tile(deck, (T, 1)))     # conservation

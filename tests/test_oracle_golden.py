@@ -149,9 +149,9 @@ def test_step_rows_and_illegal(oracle):
     state0 = env.state.copy()
     done, reward, illegal, _ = env.step(oracle.STEP_ROWS, sel, auto_reset=False)
     assert illegal.tolist() == [0, 0, 0, 1, 0, 0, 0, 0]
-    f0 = state0.reshape(11, 8, 16); f1 = env.state.reshape(11, 8, 16)
-    assert np.array_equal(f0[:, 3], f1[:, 3])  # illegal table untouched
-    assert (f1[10, [0, 1, 2, 4], 0] == 2).all()  # others advanced lord -> down
+    f0 = state0.reshape(8, 11, 16); f1 = env.state.reshape(8, 11, 16)
+    assert np.array_equal(f0[3], f1[3])  # illegal table untouched
+    assert (f1[[0, 1, 2, 4], 10, 0] == 2).all()  # others advanced lord -> down
     # choice out of range is illegal too
     env.legal()
     done, reward, illegal, _ = env.step(oracle.STEP_CHOICE, np.full(8, 10 ** 6, np.int32), auto_reset=False)
