@@ -340,47 +340,76 @@ __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
   }
 }
 
+// LDS-staged hot part of the record table: ids 0..525 (everything but planes-with-kickers
+// and four-with-two) plus the rocket in slot 526.  A launch starts with cold L2s, so a
+// record fetched from memory costs ~1000 cycles; staged once per block it costs an LDS read.
+constexpr int HOT_IDS = ID_THREE_ONE_LINE;  // 526
+constexpr int HOT_SLOTS = HOT_IDS + 1;
+struct HotTab {
+  uint4 meta[HOT_SLOTS + 1];
+  uint4 rows[HOT_SLOTS + 1];
+};
+
 // One round per 64 candidate ids [id0, id0 + count): lane tests id0 + j.
 //   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
 //             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
 // WRITE = false only counts (same code path, so count == what a later WRITE pass emits).
 template <bool WRITE, bool IDS, bool PICK>
-__device__ __forceinline__ int scan_ids(int id0, int count, uint64_t hand8, const Follow& f, int lane,
-                                        const Out& o, int n, Pick& pk) {
+__device__ __forceinline__ int scan_round(bool in, int id, uint4 m, uint4 row, uint64_t hand8, const Follow& f,
+                                          const Out& o, int n, Pick& pk) {
   constexpr uint64_t H8 = 0x8888888888888888ull;
-  for (int j0 = 0; j0 < count; j0 += 64) {
-    const int j = j0 + lane;
-    const bool in = j < count;
-    const int id = id0 + (in ? j : 0);
-    const uint4 m = g_tab[2 * id + 1];
-    uint4 row;
-    if (WRITE) row = g_tab[2 * id];
-    const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
-    const bool sub = ((hand8 - nib) & H8) == H8;
-    const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
-    const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
-                      (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
-    const bool legal = in && sub && gate;
-    const uint64_t b = __ballot(legal);
-    const int k = __popcll(b);
-    if (WRITE) {
-      const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-      if (legal) {
-        const int64_t pos = o.base + n + pre;
-        if (pos < o.cap) {
-          o.rows[pos] = row;
-          if (IDS) o.ids[pos] = id;
-        }
-      }
-      if (PICK) {
-        const int w = pk.want - n;
-        if (w >= 0 && w < k) {  // wave-uniform
-          const int src = __builtin_ctzll(__ballot(legal && pre == w));
-          pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
-        }
+  const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
+  const bool sub = ((hand8 - nib) & H8) == H8;
+  const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
+  const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
+                    (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
+  const bool legal = in && sub && gate;
+  const uint64_t b = __ballot(legal);
+  const int k = __popcll(b);
+  if (WRITE) {
+    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    if (legal) {
+      const int64_t pos = o.base + n + pre;
+      if (pos < o.cap) {
+        o.rows[pos] = row;
+        if (IDS) o.ids[pos] = id;
       }
     }
-    n += k;
+    if (PICK) {
+      const int w = pk.want - n;
+      if (w >= 0 && w < k) {  // wave-uniform
+        const int src = __builtin_ctzll(__ballot(legal && pre == w));
+        pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
+      }
+    }
+  }
+  return n + k;
+}
+
+template <bool WRITE, bool IDS, bool PICK>
+__device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, uint64_t hand8, const Follow& f,
+                                        int lane, const Out& o, int n, Pick& pk) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  if (id0 + count <= HOT_IDS || id0 == ID_BIGBANG) {  // wave-uniform: records are in LDS
+    const int slot0 = id0 == ID_BIGBANG ? HOT_IDS : id0;
+    for (int j0 = 0; j0 < count; j0 += 64) {
+      const int j = j0 + lane;
+      const bool in = j < count;
+      const int jj = in ? j : 0;
+      const uint4 m = hot.meta[slot0 + jj];
+      const uint4 row = WRITE ? hot.rows[slot0 + jj] : z;
+      n = scan_round<WRITE, IDS, PICK>(in, id0 + jj, m, row, hand8, f, o, n, pk);
+    }
+  } else {  // planes / fours: records from memory, two rounds of loads in flight
+    for (int j0 = 0; j0 < count; j0 += 128) {
+      const int ja = j0 + lane, jb = j0 + 64 + lane;
+      const bool ina = ja < count, inb = jb < count;
+      const int ida = id0 + (ina ? ja : 0), idb = id0 + (inb ? jb : 0);
+      const uint4 ma = g_tab[2 * ida + 1], mb = g_tab[2 * idb + 1];
+      const uint4 ra = WRITE ? g_tab[2 * ida] : z, rb = WRITE ? g_tab[2 * idb] : z;
+      n = scan_round<WRITE, IDS, PICK>(ina, ida, ma, ra, hand8, f, o, n, pk);
+      if (j0 + 64 < count) n = scan_round<WRITE, IDS, PICK>(inb, idb, mb, rb, hand8, f, o, n, pk);
+    }
   }
   return n;
 }
@@ -390,7 +419,7 @@ __device__ __forceinline__ int scan_ids(int id0, int count, uint64_t hand8, cons
 // admits too generously is rejected per id by scan_ids, so the planner only has to be a
 // superset -- and cheap.
 template <bool WRITE, bool IDS, bool PICK>
-__device__ int plan_scan(uint64_t hand, uint32_t info, int lane, const Out& o, Pick& pk) {
+__device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
   const Follow f = follow_of(info);
   const uint64_t hand8 = hand | 0x8888888888888888ull;
@@ -400,7 +429,7 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, int lane, const Out& o, P
   const uint32_t m3 = (uint32_t)__ballot(cnt >= 3) & M13;
   const uint32_t m4 = (uint32_t)__ballot(cnt >= 4) & M13;
   int n = 0;
-  auto scan = [&](int id0, int count) { n = scan_ids<WRITE, IDS, PICK>(id0, count, hand8, f, lane, o, n, pk); };
+  auto scan = [&](int id0, int count) { n = scan_ids<WRITE, IDS, PICK>(id0, count, hot, hand8, f, lane, o, n, pk); };
   if (!f.lead && f.lc == BIGBANG) {  // nothing beats the rocket: pass only (card.py:312-313)
     scan(0, 1);
     return n;
@@ -448,6 +477,18 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, int lane, const Out& o, P
   if (f.lead || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
     for (uint32_t qm = m4 & above; qm; qm &= qm - 1) scan(ID_FOUR_TAKE_TWO + 66 * __builtin_ctz(qm), 66);
   return n;
+}
+
+// every thread of the block copies its share of the hot records into LDS (callers issue
+// their own independent global loads first so that all of them are in flight together)
+template <int NT>
+__device__ __forceinline__ void hot_fill(HotTab& hot) {
+#pragma unroll
+  for (int i = threadIdx.x; i < HOT_SLOTS; i += NT) {
+    const int id = i < HOT_IDS ? i : ID_BIGBANG;
+    hot.meta[i] = g_tab[2 * id + 1];
+    hot.rows[i] = g_tab[2 * id];
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -533,23 +574,30 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * a.tpw;
   const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;  // wave-uniform
+  __shared__ HotTab hot;
   int64_t base = 0;
   int cnt_l = 0;      // lane i: size of the current list of table t0 + i
   int new_cnt_l = 0;  // lane i: size of the next list of table t0 + i
   int s_ply = 0, s_eps = 0, s_lord = 0;
+  // all independent global loads of the prologue are issued before anything waits
+  int part = 0, loc0 = 0;
+  uint4 Rnext = make_uint4(0, 0, 0, 0);
+  if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + t0 * STATE_ROW_BYTES))[lane];
   if (ENUM && ntab > 0) {
     // CSR base of table t0: totals of the blocks before this one + offset inside the block
-    int part = 0;
     for (int j = lane; j < (int)blockIdx.x; j += 64) part += a.cur_blk[j];
-    base = (int64_t)wave_sum(part) + a.cur_local[t0];
+    loc0 = a.cur_local[t0];
     if (lane < ntab) cnt_l = a.cur_counts[t0 + lane];
   }
+  hot_fill<TB>(hot);
+  __syncthreads();
+  if (ENUM && ntab > 0) base = (int64_t)wave_sum(part) + loc0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     STAMP(0);
     uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
-    uint4 R = make_uint4(0, 0, 0, 0);
-    if (lane < DDZ_NFIELDS) R = trow[lane];
+    uint4 R = Rnext;
+    if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
     uint64_t P = pack_row(R);
     const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
     int role = mx & 0xFF;
@@ -573,7 +621,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         pk.want = (int)__umulhi(rfl(d.x), (uint32_t)cnt);
       }
       const Out o{a.rows, a.ids, base, a.cap};
-      const int n = plan_scan<true, IDS, PICK>(hand, active ? info : QF_FROZEN, lane, o, pk);
+      const int n = plan_scan<true, IDS, PICK>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (n != cnt ? 1 : 0) | (base + cnt > a.cap ? 2 : 0);
         if (bits) atomicOr(a.status, bits);
@@ -698,7 +746,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     if (COUNT) {
       const Out none{nullptr, nullptr, 0, 0};
       Pick nopk{-1, 0, 0, 0, 0};
-      const int c = (dealt && !is_done) ? plan_scan<false, false, false>(hand, info, lane, none, nopk) : 0;
+      const int c = (dealt && !is_done) ? plan_scan<false, false, false>(hand, info, hot, lane, none, nopk) : 0;
       if (lane == i) new_cnt_l = c;
     }
     STAMP(5);
@@ -756,14 +804,17 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * MW + wv) * tpw;
   const int ntab = t0 < n ? (int)(n - t0 < tpw ? n - t0 : tpw) : 0;
+  __shared__ HotTab hot;
   int64_t base = 0;
-  int cnt_l = 0, new_cnt_l = 0;
+  int cnt_l = 0, new_cnt_l = 0, part = 0, loc0 = 0;
   if (WRITE && ntab > 0) {
-    int part = 0;
     for (int j = lane; j < (int)blockIdx.x; j += 64) part += blk_tot[j];
-    base = (int64_t)wave_sum(part) + local_off[t0];
+    loc0 = local_off[t0];
     if (lane < ntab) cnt_l = counts[t0 + lane];
   }
+  hot_fill<BLOCK>(hot);
+  __syncthreads();
+  if (WRITE && ntab > 0) base = (int64_t)wave_sum(part) + loc0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     const uint4 hr = hands[t], lr = lasts[t];
@@ -775,7 +826,7 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
       const int cnt = (int)rl((uint32_t)cnt_l, i);
       if (lane == 0) offsets[t] = (int32_t)base;
       const Out o{rows, ids, base, cap};
-      const int m = plan_scan<true, IDS, false>(hand, info, lane, o, pk);
+      const int m = plan_scan<true, IDS, false>(hand, info, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (m != cnt ? 1 : 0) | (base + cnt > cap ? 2 : 0) | ((info & QF_BADLAST) ? 4 : 0);
         if (bits) atomicOr(status, bits);
@@ -783,7 +834,7 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
       base += cnt;
     } else {
       const Out none{nullptr, nullptr, 0, 0};
-      const int c = plan_scan<false, false, false>(hand, info, lane, none, pk);
+      const int c = plan_scan<false, false, false>(hand, info, hot, lane, none, pk);
       if (lane == i) new_cnt_l = c;
     }
   }

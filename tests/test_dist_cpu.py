@@ -1,0 +1,100 @@
+"""CPU, world_size 2 (gloo): the sharding + end-of-batch trajectory gather of
+doudizhu-rl_amd/dist.py.  Per-rank trajectories come from the oracle env (the GPU engine
+is bit-identical to it, tests/test_gpu_parity.py), so this also checks that sharding by
+global table id reproduces the single-process run exactly."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ITERS = 40
+TOTAL = 37  # ragged on purpose: 19 + 18 tables
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rollout(n, base, seed):
+    from oracle import oracle
+    env = oracle.OracleEnv(n, seed=seed, gid_base=base)
+    env.reset()
+    out = np.zeros((ITERS, n, 32), np.uint8)
+    for it in range(ITERS):
+        env.legal()
+        _, _, _, traj = env.step(oracle.STEP_RANDOM, auto_reset=True, want_traj=True)
+        out[it] = traj
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ddist = importlib.import_module("doudizhu-rl_amd.dist")
+        n, base = ddist.shard_tables(TOTAL, rank, world)
+        local = torch.from_numpy(_rollout(n, base, seed=99))
+        full = ddist.gather_trajectories(local)
+        q.put((rank, n, base, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_tables_partition():
+    ddist = importlib.import_module("doudizhu-rl_amd.dist")
+    for total, world in [(37, 2), (4096, 8), (5, 8), (524288, 8)]:
+        parts = [ddist.shard_tables(total, r, world) for r in range(world)]
+        assert sum(n for n, _ in parts) == total
+        assert parts[0][1] == 0
+        for (n0, b0), (n1, b1) in zip(parts, parts[1:]):
+            assert b1 == b0 + n0 and n0 >= n1 >= n0 - 1
+    assert ddist.shard_tables(524288, 3, 8) == (65536, 3 * 65536)   # BASELINE configs[4]
+    with pytest.raises(ValueError):
+        ddist.shard_tables(8, 8, 8)
+
+
+def test_gather_trajectories_world2_matches_single_process():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(19, 0), (18, 19)]
+    single = _rollout(TOTAL, 0, seed=99)
+    for _, _, _, full in res:                      # every rank holds the full batch, global id order
+        assert full.shape == (ITERS, TOTAL, 32)
+        assert np.array_equal(full, single)
+
+
+def test_unpack_trajectory_fields():
+    ddist = importlib.import_module("doudizhu-rl_amd.dist")
+    traj = torch.from_numpy(_rollout(8, 0, seed=5))
+    f = ddist.unpack_trajectory(traj)
+    assert f["row"].shape == (ITERS, 8, 16) and f["row"].dtype == torch.int8
+    assert set(f["role"].unique().tolist()) <= {0, 1, 2}
+    assert (f["role"][0] == 1).all()                       # lord leads (game.py:173)
+    assert set(f["reward"].unique().tolist()) <= {-1, 0, 1}
+    assert ((f["reward"] != 0) == (f["done"] == 1)).all()
+    assert (f["choice"] >= 0).all() and (f["choice"] < f["n_legal"]).all()
+    assert (f["ply"][0] == 0).all() and (f["episode"][0] == 0).all()
+    assert (f["row"][..., 15] >= 0).all() and (f["row"][..., 15] <= 14).all()   # category byte
+
+
+def test_gather_without_process_group_is_identity():
+    ddist = importlib.import_module("doudizhu-rl_amd.dist")
+    t = torch.zeros((3, 4, 32), dtype=torch.uint8)
+    assert ddist.gather_trajectories(t) is t
+    with pytest.raises(ValueError):
+        ddist.gather_trajectories(torch.zeros((3, 4, 31), dtype=torch.uint8))
