@@ -99,18 +99,17 @@ def main():
     assert st["plies"] == T * K and status == 0, (st, status)
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
-    # duration of the dominant kernel (one fused k_table launch per lock-step iteration):
-    # HIP events between the launches, same stream, same workload
+    # duration of the dominant kernel (all K iterations run inside one k_rollout launch): two
+    # HIP events around that launch on the launching stream; per-iteration share = launch / n
     n_timed = min(K, 2000)
-    ms_table, _ = env.rollout_random_timed(n_timed)
+    ms_table = env.rollout_random_timed(n_timed)
     s2 = env.stats()
     mean_a2 = (s2["legal_rows"] - s1["legal_rows"]) / max(1, s2["plies"] - s1["plies"])
     # algorithmic bytes per launch (DESIGN.md "Kernels"), per table:
-    #   in : 176 state rows + 8 (list size, scan offset)      out: 176 state rows + 4 CSR offset
-    #        + 16*A legal rows + 8 (next list size, scan offset)
-    b_table = T * (372 + 16 * mean_a2)
+    #   in 176 B state rows; out 176 B state rows + 4 B list size + 16*A B legal rows
+    b_table = T * (356 + 16 * mean_a2)
     dur_table = ms_table / n_timed * 1e-3
-    dominant = "k_table"
+    dominant = "k_rollout"
     ach = b_table / dur_table / 1e9
     traffic = None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -126,8 +125,8 @@ def main():
             "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), CSR legal-move "
-                                   "list only (no NN), auto-reset; BASELINE.json configs[1]",
+            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list "
+                                   "only (no NN), auto-reset; BASELINE.json configs[1]",
                        "tables_per_gpu": T, "total_tables": total_tables,
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
                        "trajectory_gather": world > 1},

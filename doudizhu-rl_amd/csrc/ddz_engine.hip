@@ -56,7 +56,7 @@ inline Layout make_layout(int64_t T) {
   l.off_counts = o;     o = align_up(o + 2 * T * 4, 256);          // double-buffered
   l.off_local = o;      o = align_up(o + 2 * T * 4, 256);
   l.off_blk_tot = o;    o = align_up(o + 2 * l.nblk * 4, 256);
-  l.off_blk_stats = o;  o = align_up(o + l.nblk * 32, 256);
+  l.off_blk_stats = o;  o = align_up(o + T * 32, 256);           // one slot per wave (<= T)
   l.off_status = o;     o = align_up(o + 64, 256);
   l.bytes = o;
   return l;
@@ -65,7 +65,7 @@ struct Scratch {  // device pointers into the scratch buffer
   int32_t* counts[2];    // size of each table's legal list (ping-pong)
   int32_t* local_off[2]; // exclusive scan of counts inside the table's block
   int32_t* blk_tot[2];   // sum of counts per block
-  int64_t* blk_stats;    // [nblk][4] plies, episodes, lord wins, -
+  int64_t* blk_stats;    // [T][4] per block / per wave: plies, episodes, lord wins, rows
   int32_t* status;       // [0] status bits
   int64_t* legal_rows;   // running total of rows produced
 };
@@ -119,7 +119,15 @@ struct Out {
   uint4* rows;
   int32_t* ids;
   int64_t base, cap;
+  uint64_t* stage;      // EM_STAGE: per-wave LDS list of nib | category << 60, in id order
+  uint16_t* stage_ids;  //           and (IDS) the canonical ids
 };
+// what a scan does with the legal lanes
+constexpr int EM_COUNT = 0;   // nothing (list size only)
+constexpr int EM_WRITE = 1;   // rows (+ids) into the CSR list at base + running index
+constexpr int EM_PICK = 2;    // EM_WRITE + capture the row with list index pk.want
+constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS staging list
+constexpr int STAGE_CAP = 512;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py)
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
   int want;
@@ -307,15 +315,41 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 //   g_tab[2*id]     row bytes: int8 counts[15] + category (what is stored into the CSR list)
 //   g_tab[2*id + 1] {nib lo, nib hi, value | len << 8 | category << 16, 0}
 __device__ uint4 g_tab[2 * DDZ_NUM_ACTIONS];
+// Kicker combinations: for each (remains R, kickers L) pair the action space uses, the
+// L-subsets of 0..R-1 in lexicographic order (itertools.combinations, card.py:115,128,141,152),
+// L positions x 4 bits per entry.  Entry j of a list is kicker set j of an id block.
+//   list: 0 (14,2) 4+1+1 | 1 (13,2) 3+1 x2 | 2 (12,2) 4+2+2 | 3 (11,2) 3+2 x2 | 4 (12,3) 3+1 x3
+//         5 (10,3) 3+2 x3 | 6 (11,4) 3+1 x4 | 7 (9,4) 3+2 x4 | 8 (10,5) 3+1 x5
+constexpr int CL_R[9] = {14, 13, 12, 11, 12, 10, 11, 9, 10};
+constexpr int CL_L[9] = {2, 2, 2, 2, 3, 3, 4, 4, 5};
+constexpr int CL_N[9] = {91, 78, 66, 55, 220, 120, 330, 126, 252};
+constexpr int CL_OFF[10] = {0, 91, 169, 235, 290, 510, 630, 960, 1086, 1338};
+constexpr int COMBO_WORDS = 1338;
+__device__ uint32_t g_combo[COMBO_WORDS];
 __device__ uint4 g_tmp_rows[DDZ_NUM_ACTIONS];
 __device__ int32_t g_tmp_ids[DDZ_NUM_ACTIONS];
 
 // one wavefront: enumerate the full deck on lead (every action, ids 1..13526 in order)
 __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
   const int lane = threadIdx.x & 63;
+  if (lane < 9) {  // lane k writes combination list k
+    const int R = CL_R[lane], L = CL_L[lane];
+    int idx[5] = {0, 1, 2, 3, 4};
+    for (int e = 0; e < CL_N[lane]; ++e) {
+      uint32_t w = 0;
+      for (int k = 0; k < L; ++k) w |= (uint32_t)idx[k] << (4 * k);
+      g_combo[CL_OFF[lane] + e] = w;
+      int i = L - 1;
+      while (i >= 0 && idx[i] == R - L + i) --i;
+      if (i >= 0) {
+        ++idx[i];
+        for (int j = i + 1; j < L; ++j) idx[j] = idx[j - 1] + 1;
+      }
+    }
+  }
   const uint32_t lut = c_line_lut.v[lane];
   const uint64_t deck = 0x0114444444444444ull;  // 4 of 3..2, one of each joker
-  Out o{g_tmp_rows, g_tmp_ids, 0, DDZ_NUM_ACTIONS};
+  Out o{g_tmp_rows, g_tmp_ids, 0, DDZ_NUM_ACTIONS, nullptr, nullptr};
   Pick pk{-1, 0, 0, 0, 0};
   const int n = enumerate_table<true, false>(deck, mk_info(EMPTY, 0, 1), lut, lane, o, pk);
   __threadfence();
@@ -348,68 +382,90 @@ constexpr int HOT_SLOTS = HOT_IDS + 1;
 struct HotTab {
   uint4 meta[HOT_SLOTS + 1];
   uint4 rows[HOT_SLOTS + 1];
+  uint32_t combo[COMBO_WORDS + 2];
 };
 
-// One round per 64 candidate ids [id0, id0 + count): lane tests id0 + j.
-//   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
-//             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
-// WRITE = false only counts (same code path, so count == what a later WRITE pass emits).
-template <bool WRITE, bool IDS, bool PICK>
-__device__ __forceinline__ int scan_round(bool in, int id, uint4 m, uint4 row, uint64_t hand8, const Follow& f,
-                                          const Out& o, int n, Pick& pk) {
-  constexpr uint64_t H8 = 0x8888888888888888ull;
-  const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
-  const bool sub = ((hand8 - nib) & H8) == H8;
-  const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
-  const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
-                    (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
-  const bool legal = in && sub && gate;
+// the action a lane is looking at, however its record was obtained
+template <int EM, bool IDS>
+__device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int cat, uint4 row, const Out& o, int n,
+                                         Pick& pk) {
   const uint64_t b = __ballot(legal);
   const int k = __popcll(b);
-  if (WRITE) {
+  if (EM != EM_COUNT) {
     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-    if (legal) {
-      const int64_t pos = o.base + n + pre;
-      if (pos < o.cap) {
-        o.rows[pos] = row;
-        if (IDS) o.ids[pos] = id;
+    if (EM == EM_STAGE) {
+      if (legal && n + pre < STAGE_CAP) {
+        o.stage[n + pre] = nib | ((uint64_t)cat << 60);
+        if (IDS) o.stage_ids[n + pre] = (uint16_t)id;
       }
-    }
-    if (PICK) {
-      const int w = pk.want - n;
-      if (w >= 0 && w < k) {  // wave-uniform
-        const int src = __builtin_ctzll(__ballot(legal && pre == w));
-        pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
+    } else {
+      if (legal) {
+        const int64_t pos = o.base + n + pre;
+        if (pos < o.cap) {
+          o.rows[pos] = row;
+          if (IDS) o.ids[pos] = id;
+        }
+      }
+      if (EM == EM_PICK) {
+        const int w = pk.want - n;
+        if (w >= 0 && w < k) {  // wave-uniform
+          const int src = __builtin_ctzll(__ballot(legal && pre == w));
+          pk.r0 = rl(row.x, src); pk.r1 = rl(row.y, src); pk.r2 = rl(row.z, src); pk.r3 = rl(row.w, src);
+        }
       }
     }
   }
   return n + k;
 }
 
-template <bool WRITE, bool IDS, bool PICK>
+// ids [id0, id0 + count) of the hot part of the action space (or the rocket): records in LDS.
+//   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
+//             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
+template <int EM, bool IDS>
 __device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, uint64_t hand8, const Follow& f,
                                         int lane, const Out& o, int n, Pick& pk) {
-  const uint4 z = make_uint4(0, 0, 0, 0);
-  if (id0 + count <= HOT_IDS || id0 == ID_BIGBANG) {  // wave-uniform: records are in LDS
-    const int slot0 = id0 == ID_BIGBANG ? HOT_IDS : id0;
-    for (int j0 = 0; j0 < count; j0 += 64) {
-      const int j = j0 + lane;
-      const bool in = j < count;
-      const int jj = in ? j : 0;
-      const uint4 m = hot.meta[slot0 + jj];
-      const uint4 row = WRITE ? hot.rows[slot0 + jj] : z;
-      n = scan_round<WRITE, IDS, PICK>(in, id0 + jj, m, row, hand8, f, o, n, pk);
+  constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
+  constexpr uint64_t H8 = 0x8888888888888888ull;
+  const int slot0 = id0 == ID_BIGBANG ? HOT_IDS : id0;
+  for (int j0 = 0; j0 < count; j0 += 64) {
+    const int j = j0 + lane;
+    const bool in = j < count;
+    const int jj = in ? j : 0, id = id0 + jj;
+    const uint4 m = hot.meta[slot0 + jj];
+    const uint4 row = ROWS ? hot.rows[slot0 + jj] : make_uint4(0, 0, 0, 0);
+    const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
+    const bool sub = ((hand8 - nib) & H8) == H8;
+    const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
+    const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
+                      (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
+    n = scan_emit<EM, IDS>(in && sub && gate, id, nib, cat, row, o, n, pk);
+  }
+  return n;
+}
+
+// one id block of a category with kickers (card.py:110-129, :139-153): main group `mainnib`
+// (ranks [s, s + gap) removed from the remains list), kicker set j = combination list entry j
+// with `mult` cards per kicker; ids idb + j.  The planner has already applied the follow
+// filter (category, len, value are those of the block), so legal <=> subset of the hand.
+template <int EM, bool IDS>
+__device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_t mainnib, int s, int gap, int mult,
+                                           int cat, const HotTab& hot, uint64_t hand8, int lane, const Out& o,
+                                           int n, Pick& pk) {
+  constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
+  constexpr uint64_t H8 = 0x8888888888888888ull;
+  const int L = CL_L[list], off = CL_OFF[list];
+  for (int j0 = 0; j0 < count; j0 += 64) {
+    const int j = j0 + lane;
+    const bool in = j < count;
+    const uint32_t e = hot.combo[off + (in ? j : 0)];
+    uint64_t nib = mainnib;
+    for (int k = 0; k < L; ++k) {
+      const int pos = (e >> (4 * k)) & 15;
+      nib += (uint64_t)mult << (4 * (pos < s ? pos : pos + gap));
     }
-  } else {  // planes / fours: records from memory, two rounds of loads in flight
-    for (int j0 = 0; j0 < count; j0 += 128) {
-      const int ja = j0 + lane, jb = j0 + 64 + lane;
-      const bool ina = ja < count, inb = jb < count;
-      const int ida = id0 + (ina ? ja : 0), idb = id0 + (inb ? jb : 0);
-      const uint4 ma = g_tab[2 * ida + 1], mb = g_tab[2 * idb + 1];
-      const uint4 ra = WRITE ? g_tab[2 * ida] : z, rb = WRITE ? g_tab[2 * idb] : z;
-      n = scan_round<WRITE, IDS, PICK>(ina, ida, ma, ra, hand8, f, o, n, pk);
-      if (j0 + 64 < count) n = scan_round<WRITE, IDS, PICK>(inb, idb, mb, rb, hand8, f, o, n, pk);
-    }
+    const bool sub = ((hand8 - nib) & H8) == H8;
+    const uint4 row = ROWS ? unpack_row(nib, (uint32_t)cat) : make_uint4(0, 0, 0, 0);
+    n = scan_emit<EM, IDS>(in && sub, idb + j, nib, cat, row, o, n, pk);
   }
   return n;
 }
@@ -418,7 +474,7 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, u
 // (wave-uniform, scalar); ranges are visited in ascending id order.  Everything a range
 // admits too generously is rejected per id by scan_ids, so the planner only has to be a
 // superset -- and cheap.
-template <bool WRITE, bool IDS, bool PICK>
+template <int EM, bool IDS>
 __device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
   const Follow f = follow_of(info);
@@ -429,7 +485,7 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int la
   const uint32_t m3 = (uint32_t)__ballot(cnt >= 3) & M13;
   const uint32_t m4 = (uint32_t)__ballot(cnt >= 4) & M13;
   int n = 0;
-  auto scan = [&](int id0, int count) { n = scan_ids<WRITE, IDS, PICK>(id0, count, hot, hand8, f, lane, o, n, pk); };
+  auto scan = [&](int id0, int count) { n = scan_ids<EM, IDS>(id0, count, hot, hand8, f, lane, o, n, pk); };
   if (!f.lead && f.lc == BIGBANG) {  // nothing beats the rocket: pass only (card.py:312-313)
     scan(0, 1);
     return n;
@@ -458,24 +514,51 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int la
   } else if (f.lc == TRIPLE_LINE) {
     scan(ID_TRIPLE_LINE, 45);
   }
-  // planes with kickers (card.py:110-129): one id block per (start, len), canonical order
-  auto planes = [&](int cat, int nranks, int hi, bool skipj, int idb) {
-    if (!(f.lead || f.lc == cat) || (m3 & (m3 >> 1) & M12) == 0) return;
-    for (int s = 0; s <= 10; ++s)
-      for (int L = 2; L <= hi && s + L <= 12; ++L) {
-        const uint32_t run = ((1u << L) - 1u) << s;
-        const int size = binom(nranks - L, L) - ((skipj && L == 2) ? 1 : 0);
-        if ((m3 & run) == run && (f.lead || (L == f.ll && s > f.lv))) scan(idb, size);
-        idb += size;
+  // planes with kickers (card.py:110-129): one id block per (start s, len L), canonical
+  // order = s-major, L ascending.  Only starts of triple runs are visited; the id of a block
+  // is closed-form: blocks before start s plus the shorter blocks of s.
+  //   3+1: sizes C(15-L, L) = 77*, 220, 330, 252 (L = 2..5; * joker pair dropped, card.py:116)
+  //   3+2: sizes C(13-L, L) = 55, 120, 126        (L = 2..4)
+  auto planes = [&](int cat, int hi, int idb0, int mult, int list2, int list3, int list4, int list5) {
+    const uint32_t mm = m3 & M12;
+    if (!(f.lead || f.lc == cat)) return;
+    for (uint32_t st = mm & (mm >> 1); st; st &= st - 1) {
+      const int s = __builtin_ctz(st);
+      const int runlen = __builtin_ctz(~(mm >> s));  // consecutive triples from s
+      int before, sz2, sz3, sz4;
+      if (cat == THREE_ONE_LINE) {
+        before = 879 * (s < 8 ? s : 8) + (s > 8 ? 627 : 0) + (s > 9 ? 297 : 0);
+        sz2 = 77; sz3 = 220; sz4 = 330;
+      } else {
+        before = 301 * (s < 9 ? s : 9) + (s > 9 ? 175 : 0);
+        sz2 = 55; sz3 = 120; sz4 = 126;
       }
+      const int maxL = runlen < hi ? runlen : hi;
+      for (int L = 2; L <= maxL && s + L <= 12; ++L) {
+        if (!(f.lead || (L == f.ll && s > f.lv))) continue;
+        const int idb = idb0 + before + (L > 2 ? sz2 : 0) + (L > 3 ? sz3 : 0) + (L > 4 ? sz4 : 0);
+        const int size = L == 2 ? sz2 : L == 3 ? sz3 : L == 4 ? sz4 : 252;
+        const int list = L == 2 ? list2 : L == 3 ? list3 : L == 4 ? list4 : list5;
+        const uint64_t mainnib = ((3ull * ONES) & ((1ull << (4 * L)) - 1ull)) << (4 * s);
+        n = scan_combos<EM, IDS>(list, size, idb, mainnib, s, L, mult, cat, hot, hand8, lane, o, n, pk);
+      }
+    }
   };
-  planes(THREE_ONE_LINE, 15, 5, true, ID_THREE_ONE_LINE);
-  planes(THREE_TWO_LINE, 13, 4, false, ID_THREE_TWO_LINE);
+  planes(THREE_ONE_LINE, 5, ID_THREE_ONE_LINE, 1, 1, 4, 6, 8);
+  planes(THREE_TWO_LINE, 4, ID_THREE_TWO_LINE, 2, 3, 5, 7, 7);
   if ((m1 & JOKERS) == JOKERS) scan(ID_BIGBANG, 1);  // rocket (card.py:134, :314-315)
-  if (f.lead || f.lc == FOUR_TAKE_ONE)                // card.py:139-143
-    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) scan(ID_FOUR_TAKE_ONE + 90 * __builtin_ctz(qm), 90);
+  if (f.lead || f.lc == FOUR_TAKE_ONE)                // card.py:139-143 (no joker pair: :142)
+    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
+      const int q = __builtin_ctz(qm);
+      n = scan_combos<EM, IDS>(0, 90, ID_FOUR_TAKE_ONE + 90 * q, 4ull << (4 * q), q, 1, 1, FOUR_TAKE_ONE, hot, hand8,
+                               lane, o, n, pk);
+    }
   if (f.lead || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
-    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) scan(ID_FOUR_TAKE_TWO + 66 * __builtin_ctz(qm), 66);
+    for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
+      const int q = __builtin_ctz(qm);
+      n = scan_combos<EM, IDS>(2, 66, ID_FOUR_TAKE_TWO + 66 * q, 4ull << (4 * q), q, 1, 2, FOUR_TAKE_TWO, hot, hand8,
+                               lane, o, n, pk);
+    }
   return n;
 }
 
@@ -489,6 +572,8 @@ __device__ __forceinline__ void hot_fill(HotTab& hot) {
     hot.meta[i] = g_tab[2 * id + 1];
     hot.rows[i] = g_tab[2 * id];
   }
+#pragma unroll
+  for (int i = threadIdx.x; i < COMBO_WORDS; i += NT) hot.combo[i] = g_combo[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -507,11 +592,11 @@ __device__ inline void deal_wave(uint64_t gid, uint32_t episode, uint32_t k0, ui
   const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (1u << 16) | (uint32_t)(lane >> 2)), k0, k1);
   const int w = lane & 3;
   const uint32_t key = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+  // rank by (key, card index): one 64-bit compare of (key << 6 | index) per card
+  const uint64_t kk = ((uint64_t)key << 6) | (uint32_t)lane;
   int pos = 0;
-  for (int j = 0; j < 54; ++j) {
-    const uint32_t kj = rl(key, j);
-    pos += (kj < key || (kj == key && j < lane)) ? 1 : 0;
-  }
+#pragma unroll 6
+  for (int j = 0; j < 54; ++j) pos += rl64(kk, j) < kk ? 1 : 0;
   const bool card = lane < 54;
   o0 = nib_from_cards(__ballot(card && pos < 17));
   o1 = nib_from_cards(__ballot(card && pos >= 17 && pos < 37));
@@ -620,8 +705,8 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
         pk.want = (int)__umulhi(rfl(d.x), (uint32_t)cnt);
       }
-      const Out o{a.rows, a.ids, base, a.cap};
-      const int n = plan_scan<true, IDS, PICK>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
+      const Out o{a.rows, a.ids, base, a.cap, nullptr, nullptr};
+      const int n = plan_scan<PICK ? EM_PICK : EM_WRITE, IDS>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (n != cnt ? 1 : 0) | (base + cnt > a.cap ? 2 : 0);
         if (bits) atomicOr(a.status, bits);
@@ -744,9 +829,9 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     }
     STAMP(4);
     if (COUNT) {
-      const Out none{nullptr, nullptr, 0, 0};
+      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr};
       Pick nopk{-1, 0, 0, 0, 0};
-      const int c = (dealt && !is_done) ? plan_scan<false, false, false>(hand, info, hot, lane, none, nopk) : 0;
+      const int c = (dealt && !is_done) ? plan_scan<EM_COUNT, false>(hand, info, hot, lane, none, nopk) : 0;
       if (lane == i) new_cnt_l = c;
     }
     STAMP(5);
@@ -789,6 +874,144 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_rollout: the random-policy lock-step iteration (game.py:169-181 with envi.py:79-85) with
+// NO dependency between tables: every table owns a fixed-stride slab of the list buffer
+// (rows[t * stride ...], counts[t]), so there is no cross-table scan, no count pass and no
+// block barrier after the prologue.  One wavefront per table:
+//   scan once, staging nib|category of every legal move in the wave's LDS list (its length
+//   is the list size, known before the pick) -> flush the list as coalesced 16-byte rows
+//   -> pick by engine RNG from the staged list -> apply / terminal / deal -> store state.
+struct RolloutArgs {
+  uint8_t* state;
+  int64_t T;
+  int tpw;
+  uint32_t k0, k1;
+  uint64_t gid_base;
+  int32_t* counts;   // [T] list sizes
+  uint4* rows;       // [T][stride] list slabs
+  int32_t* ids;      // [T][stride] or null
+  int64_t stride;
+  int64_t n_iters;   // lock-step iterations run inside this launch
+  uint4* traj;       // [n_iters][T][2] or null
+  int64_t* wave_stats;
+  int32_t* status;
+  int64_t* legal_rows;
+};
+
+template <bool IDS>
+__global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
+#ifdef DDZ_STAMP
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+  __shared__ HotTab hot;
+  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
+  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
+  const int64_t t0 = wave * a.tpw;
+  const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;
+  uint4 Rnext = make_uint4(0, 0, 0, 0);
+  if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + t0 * STATE_ROW_BYTES))[lane];
+  hot_fill<TB>(hot);
+  __syncthreads();
+  uint64_t* stage = s_stage[wv];
+  uint16_t* sid = s_sid[IDS ? wv : 0];
+  int s_ply = 0, s_eps = 0, s_lord = 0;
+  int64_t s_rows = 0;
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+#ifdef DDZ_STAMP
+    if (g_stamps && lane == 0) g_stamps[8 * t + 7] = t_entry;
+#endif
+    STAMP(0);
+    uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
+    uint4 R = Rnext;
+    if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
+    // the table's 11 rows stay in registers for all iterations of this launch; every
+    // iteration still stores its list, its state and its trajectory record to HBM
+    for (int64_t it = 0; it < a.n_iters; ++it) {
+    const uint64_t P = pack_row(R);
+    const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
+    int role = mx & 0xFF;
+    if (role > 2) role = 0;
+    const bool is_done = (mx >> 8) & 0xFF, dealt = (my >> 16) & 0xFF;
+    uint32_t ply = my & 0xFFFF, episode = mz;
+    const uint64_t gid = a.gid_base + (uint64_t)t;
+    const bool active = dealt && !is_done;
+    const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+    const uint64_t hand = rl64(P, DDZ_F_HAND0 + role);
+    const uint32_t info = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
+                                    rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+    // the draw of this ply does not depend on the list: issue it before the scan
+    const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
+    const Out o{nullptr, nullptr, 0, 0, stage, sid};
+    Pick pk{-1, 0, 0, 0, 0};
+    STAMP(1);
+    int n = plan_scan<EM_STAGE, IDS>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
+    __builtin_amdgcn_wave_barrier();
+    if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
+      if (lane == 0) atomicOr(a.status, 2);
+      n = 0;
+    }
+    STAMP(2);
+    if (lane == 0) a.counts[t] = n;
+    s_rows += n;
+    const int64_t base = t * a.stride;
+    for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
+      const uint64_t e = stage[j];
+      a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
+      if (IDS) a.ids[base + j] = sid[j];
+    }
+    STAMP(3);
+    uint4 tr0 = make_uint4(0, 0, 0, 0);
+    uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)n & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
+    if (!active || n <= 0) {
+      tr1.x |= (uint32_t)is_done << 8 | 2u << 24;  // frozen table
+    } else {
+      const int idx = (int)__umulhi(rfl(d.x), (uint32_t)n);  // random.choice(actions), envi.py:83
+      const uint64_t e = stage[idx];
+      const uint4 c = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
+      const uint32_t c0 = rfl(c.x), c1 = rfl(c.y), c2 = rfl(c.z), c3 = rfl(c.w);
+      const uint32_t cw3 = c3 & 0x00FFFFFFu;
+      const uint32_t ncards = (uint32_t)nib_sum(e & 0x0FFFFFFFFFFFFFFFull);
+      if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
+        R.x -= c0; R.y -= c1; R.z -= c2; R.w -= cw3 + (ncards << 24);
+      } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
+        R.x += c0; R.y += c1; R.z += c2; R.w += cw3;
+      } else if (lane == DDZ_F_RECENT0 + role) {
+        R = make_uint4(c0, c1, c2, c3);
+      }
+      const bool won = (rl(R.w, DDZ_F_HAND0 + role) >> 24) == 0;
+      const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
+      s_ply += 1; s_eps += won; s_lord += (won && role == 1);
+      tr0 = make_uint4(c0, c1, c2, c3);
+      tr1.x |= (uint32_t)won << 8 | o_reward << 16;
+      tr1.w = (uint32_t)idx;
+      ply += 1;
+      if (won) {  // auto-reset: next episode of this table
+        episode += 1;
+        uint64_t h0, h1, h2;
+        deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
+        R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+            : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
+      } else if (lane == DDZ_F_META) {
+        R = make_uint4((uint32_t)rp1 | (0xFFu << 16), (my & 0xFFFF0000u) | (ply & 0xFFFF), mz, R.w);
+      }
+      if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
+    }
+    if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
+    STAMP(4);
+    __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
+    }
+  }
+  if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
+    int64_t* ws = a.wave_stats + 4 * wave;
+    ws[0] += s_ply; ws[1] += s_eps; ws[2] += s_lord; ws[3] += s_rows;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // stateless path: r.get_moves(hand15, last15) for n independent (hand, last) pairs, one
 // wavefront per query (tpw consecutive queries per wave); pass 1 (WRITE = false) sizes the
 // lists and scans them per block, pass 2 writes the CSR list.
@@ -825,16 +1048,16 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
     if (WRITE) {
       const int cnt = (int)rl((uint32_t)cnt_l, i);
       if (lane == 0) offsets[t] = (int32_t)base;
-      const Out o{rows, ids, base, cap};
-      const int m = plan_scan<true, IDS, false>(hand, info, hot, lane, o, pk);
+      const Out o{rows, ids, base, cap, nullptr, nullptr};
+      const int m = plan_scan<EM_WRITE, IDS>(hand, info, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (m != cnt ? 1 : 0) | (base + cnt > cap ? 2 : 0) | ((info & QF_BADLAST) ? 4 : 0);
         if (bits) atomicOr(status, bits);
       }
       base += cnt;
     } else {
-      const Out none{nullptr, nullptr, 0, 0};
-      const int c = plan_scan<false, false, false>(hand, info, hot, lane, none, pk);
+      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr};
+      const int c = plan_scan<EM_COUNT, false>(hand, info, hot, lane, none, pk);
       if (lane == i) new_cnt_l = c;
     }
   }
@@ -865,26 +1088,26 @@ __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ ro
   if (t < n) out[t] = classify(pack_row(rows[t]));
 }
 
-// stats[0..3] += {plies, episodes, legal rows, lord wins}; block slots are cleared
-__global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nblk, int64_t* stats) {
-  __shared__ long long sh[3][BLOCK];
-  long long v[3] = {0, 0, 0};
-  for (int64_t b = threadIdx.x; b < nblk; b += BLOCK)
-    for (int k = 0; k < 3; ++k) {
+// stats[0..3] += {plies, episodes, legal rows, lord wins}; the slots are cleared
+__global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nslots, int64_t* stats) {
+  __shared__ long long sh[4][BLOCK];
+  long long v[4] = {0, 0, 0, 0};
+  for (int64_t b = threadIdx.x; b < nslots; b += BLOCK)
+    for (int k = 0; k < 4; ++k) {
       v[k] += sc.blk_stats[4 * b + k];
       sc.blk_stats[4 * b + k] = 0;
     }
-  for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] = v[k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
   for (int d = BLOCK / 2; d > 0; d >>= 1) {
     if ((int)threadIdx.x < d)
-      for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
+      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     stats[0] += sh[0][0];
     stats[1] += sh[1][0];
-    stats[2] += *sc.legal_rows;
+    stats[2] += *sc.legal_rows + sh[3][0];
     stats[3] += sh[2][0];
     *sc.legal_rows = 0;
   }
@@ -1226,75 +1449,67 @@ int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {
   if (!stats) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, e->sc, e->nblocks, stats);
+  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, e->sc, e->T, stats);
   return check_launch();
 }
 
-int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap,
+static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
+                          uint8_t* traj, hipStream_t st) {
+  RolloutArgs a;
+  a.state = e->state; a.T = e->T; a.tpw = e->tpw;
+  a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
+  a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride; a.n_iters = n_iters;
+  a.traj = (uint4*)traj;
+  a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
+  const dim3 grid((unsigned)e->nblocks), block(TB);
+  if (ids) hipLaunchKernelGGL(k_rollout<true>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(k_rollout<false>, grid, block, 0, st, a);
+  e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
+  return check_launch();
+}
+
+int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
                        int64_t* stats, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (n_iters < 0 || !offsets || !rows || cap < 0) return DDZ_EINVAL;
-  if (cap > 0x7FFFFFFF) return DDZ_ECAP;
+  if (n_iters < 0 || !counts || !rows || stride < 1) return DDZ_EINVAL;
+  if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   hipStream_t st = (hipStream_t)stream;
-  e->legal_cap = cap;
-  Io io;
-  io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap; io.auto_reset = 1;
-  for (int64_t it = 0; it < n_iters; ++it) {
-    int rc = ensure_counts(e, st);
-    if (rc) return rc;
-    io.traj = traj ? traj + it * e->T * DDZ_TRAJ_BYTES : nullptr;
-    rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);  // one launch per lock-step iteration
+  if (n_iters > 0) {  // tables do not depend on each other: all iterations run inside one launch
+    int rc = launch_rollout(e, n_iters, counts, rows, ids, stride, traj, st);
     if (rc) return rc;
   }
   if (stats) {
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, st, e->sc, e->nblocks, stats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(BLOCK), 0, st, e->sc, e->T, stats);
     return check_launch();
   }
   return DDZ_OK;
 }
 
-int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8_t* rows, int32_t* ids,
-                             int64_t cap, double* ms, void* stream) {
+int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids,
+                             int64_t stride, double* ms, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (n_iters <= 0 || n_iters > 100000 || !offsets || !rows || cap < 0 || !ms) return DDZ_EINVAL;
-  if (cap > 0x7FFFFFFF) return DDZ_ECAP;
+  if (n_iters <= 0 || !counts || !rows || stride < 1 || !ms) return DDZ_EINVAL;
+  if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   hipStream_t st = (hipStream_t)stream;
-  e->legal_cap = cap;
-  int rc = ensure_counts(e, st);
-  if (rc) return rc;
-  const int64_t nev = n_iters + 1;
-  hipEvent_t* ev = (hipEvent_t*)calloc((size_t)nev, sizeof(hipEvent_t));
-  if (!ev) return DDZ_EINVAL;
-  int64_t made = 0;
-  for (; made < nev; ++made)
-    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = hip_fail(hipGetLastError()); break; }
+  hipEvent_t ev[2];
+  if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) return hip_fail(hipGetLastError());
+  (void)hipEventRecord(ev[0], st);
+  int rc = launch_rollout(e, n_iters, counts, rows, ids, stride, nullptr, st);
+  (void)hipEventRecord(ev[1], st);
+  hipError_t r = hipStreamSynchronize(st);
+  if (rc == DDZ_OK && r != hipSuccess) rc = hip_fail(r);
   if (rc == DDZ_OK) {
-    Io io;
-    io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap; io.auto_reset = 1;
-    (void)hipEventRecord(ev[0], st);
-    for (int64_t it = 0; it < n_iters && rc == DDZ_OK; ++it) {
-      rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);
-      (void)hipEventRecord(ev[it + 1], st);
-    }
-    hipError_t r = hipStreamSynchronize(st);
-    if (r != hipSuccess) rc = hip_fail(r);
-    if (rc == DDZ_OK) {
-      double tot = 0;
-      for (int64_t it = 0; it < n_iters; ++it) {
-        float x = 0;
-        (void)hipEventElapsedTime(&x, ev[it], ev[it + 1]);
-        tot += x;
-      }
-      ms[0] = tot;
-      ms[1] = 0;
-    }
+    float x = 0;
+    (void)hipEventElapsedTime(&x, ev[0], ev[1]);
+    ms[0] = x;  // duration of the one k_rollout launch that ran the n_iters iterations
+    ms[1] = (double)n_iters;
   }
-  for (int64_t i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
-  free(ev);
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
   return rc;
 }
 

@@ -63,6 +63,7 @@ class BatchedEnv:
         self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.rows = torch.zeros((self.cap, ROW), dtype=torch.int8, device=d)
         self.ids = torch.zeros(self.cap, dtype=torch.int32, device=d) if want_ids else None
+        self.counts = torch.zeros(self.T, dtype=torch.int32, device=d)  # slab layout: list sizes
         self.done = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
@@ -162,24 +163,45 @@ class BatchedEnv:
         total = int(self.offsets[-1].item())
         return rows_to_onehot(self.rows[:total])
 
+    # ---- random-policy rollout, slab layout ----
+    @property
+    def slab_stride(self):
+        """rows per table slab when self.rows is used in the slab layout"""
+        return self.cap // self.T
+
+    def slab_rows(self):
+        """[T, stride, 16] view of the list buffer after rollout_random: table t's legal
+        moves are slab_rows()[t, :counts[t]] (ascending canonical id)."""
+        st = self.slab_stride
+        return self.rows[: self.T * st].view(self.T, st, ROW)
+
+    def slab_ids(self):
+        st = self.slab_stride
+        return None if self.ids is None else self.ids[: self.T * st].view(self.T, st)
+
     def rollout_random(self, n_iters, traj=None):
-        """n_iters lock-step iterations of {legal, step_random(auto_reset)} (game.py:169-181)."""
+        """n_iters lock-step iterations of {legal list, step_random(auto_reset)}
+        (game.py:169-181 with envi.py:79-85), one kernel launch each.  The lists of the last
+        iteration's *pre-step* states are left in the slab layout (counts, slab_rows())."""
+        if self.slab_stride < MAX_LEGAL_PER_TABLE:
+            raise ValueError(f"rollout needs row_capacity >= {MAX_LEGAL_PER_TABLE} * n_tables")
         if traj is not None and (traj.dtype != torch.uint8 or not traj.is_contiguous()
                                  or traj.numel() != n_iters * self.T * TRAJ_BYTES):
             raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
-        check(self.lib.ddz_rollout_random(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
-                                          _p(self.ids), self.cap, _p(self._stats), _p(traj),
+        check(self.lib.ddz_rollout_random(self._h, int(n_iters), _p(self.counts), _p(self.rows),
+                                          _p(self.ids), self.slab_stride, _p(self._stats), _p(traj),
                                           _stream(self.device)))
         self._legal_fresh = False
 
     def rollout_random_timed(self, n_iters):
-        """Same loop with a hipEvent between the kernels; returns (ms_enumerate, ms_step)
-        summed over n_iters.  Synchronises; measurement aid for bench.py."""
+        """Same loop between two hipEvents; returns the elapsed ms of the n_iters launches.
+        Synchronises; measurement aid for bench.py."""
         ms = (C.c_double * 2)()
-        check(self.lib.ddz_rollout_random_timed(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
-                                                _p(self.ids), self.cap, ms, _stream(self.device)))
+        check(self.lib.ddz_rollout_random_timed(self._h, int(n_iters), _p(self.counts), _p(self.rows),
+                                                _p(self.ids), self.slab_stride, ms,
+                                                _stream(self.device)))
         self._legal_fresh = False
-        return ms[0], ms[1]
+        return ms[0]
 
     def stats(self):
         """{plies, episodes, legal_rows, lord_wins} accumulated so far (host sync)."""

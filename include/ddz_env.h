@@ -117,19 +117,26 @@ int ddz_get_moves(int device_id, const int8_t* hands, const int8_t* lasts, int64
                   void* scratch, int64_t scratch_bytes, void* stream);
 
 /* The lock-step loop of Game.play under a random policy (game.py:169-181 with
- * envi.py:79-85), n_iters iterations of {legal, step_random(auto_reset)} enqueued
- * back to back.  stats (device, int64[4], may be NULL) accumulates
- * {plies, finished episodes, total legal rows, lord wins}; traj (may be NULL) is
- * u8[n_iters][T][32].                                                                  */
-int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
-                       int32_t* ids, int64_t row_capacity, int64_t* stats, uint8_t* traj,
+ * envi.py:79-85): n_iters iterations of {legal list, step_random(auto_reset)} in ONE kernel
+ * launch.  The lists are written in the SLAB layout: table t owns
+ * rows[t * stride .. t * stride + counts[t]) (ascending canonical id, same rows as
+ * ddz_legal), so no table depends on another: a wavefront keeps its table's rows in
+ * registers across the iterations and stores the list, the state and the trajectory
+ * record of EVERY iteration (each iteration overwrites the table's slab; after the call
+ * counts/rows hold the lists of the last pre-step states).
+ *   counts int32[T]; rows int8[T * stride][16]; ids int32[T * stride] or NULL;
+ *   stride >= 512 covers every list of a <= 20-card hand (497 is the maximum);
+ *   stats (device, int64[4], may be NULL) accumulates {plies, finished episodes, total legal
+ *   rows, lord wins}; traj (may be NULL) is u8[n_iters][T][32].                            */
+int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t* rows,
+                       int32_t* ids, int64_t stride, int64_t* stats, uint8_t* traj,
                        void* stream);
 
-/* Measurement aid: the same loop with a hipEvent between the kernels, on `stream`.
- * ms (HOST, double[2]) receives the summed durations of the enumerate and of the step
- * kernels; synchronises the stream.  Used by bench.py for the roofline figures.           */
-int ddz_rollout_random_timed(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
-                             int32_t* ids, int64_t row_capacity, double* ms, void* stream);
+/* Measurement aid: the same loop between two hipEvents on `stream`.  ms (HOST, double[2])
+ * receives {elapsed ms of the launch, n_iters}; synchronises the stream.
+ * Used by bench.py for the roofline figure.                                                */
+int ddz_rollout_random_timed(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t* rows,
+                             int32_t* ids, int64_t stride, double* ms, void* stream);
 
 /* stats (device, int64[4]) += {plies, finished episodes, legal rows, lord wins} accumulated by
  * ddz_step / ddz_legal since the last read; the internal accumulators are cleared.        */

@@ -136,6 +136,39 @@ def test_lockstep_vs_oracle(pkg, oracle, T, iters, seed, base):
     assert s["plies"] == T * iters
 
 
+@pytest.mark.parametrize("T,iters,seed,base", [(777, 140, 3, 0), (4096, 30, 8, 9876543210)])
+def test_rollout_slabs_vs_oracle(pkg, oracle, T, iters, seed, base):
+    """the fused rollout kernel (slab layout): after launches of 1..4 in-kernel iterations the
+    list of every table, its ids, every iteration's trajectory record and the whole packed
+    state equal the oracle's."""
+    env = pkg.BatchedEnv(T, seed=seed, table_id_base=base)
+    ref = oracle.OracleEnv(T, seed=seed, gid_base=base)
+    env.reset(); ref.reset()
+    it = 0
+    while it < iters:
+        n = 1 + (it % 4)
+        traj = torch.zeros((n, T, 32), dtype=torch.uint8, device=_dev())
+        rtrajs = []
+        for _ in range(n):
+            roff, rrows, rids = ref.legal()
+            roff = roff.copy(); rrows = rrows.copy(); rids = rids.copy()
+            _, _, _, rtraj = ref.step(oracle.STEP_RANDOM, auto_reset=True, want_traj=True)
+            rtrajs.append(rtraj)
+        env.rollout_random(n, traj=traj)
+        counts = env.counts.cpu().numpy()
+        assert np.array_equal(counts, np.diff(roff)), it      # lists of the last pre-step state
+        slab = env.slab_rows().cpu().numpy(); sids = env.slab_ids().cpu().numpy()
+        mask = np.arange(env.slab_stride)[None, :] < counts[:, None]
+        assert np.array_equal(slab[mask], rrows), it           # row-major gather == CSR order
+        assert np.array_equal(sids[mask], rids), it
+        assert np.array_equal(traj.cpu().numpy(), np.stack(rtrajs)), it
+        assert np.array_equal(env.state.cpu().numpy(), ref.state), it
+        it += n
+    assert env.status() == 0
+    s = env.stats()
+    assert s["plies"] == T * it and s["legal_rows"] > 0
+
+
 def test_no_auto_reset_freezes_tables(pkg, oracle):
     T = 512
     env = pkg.BatchedEnv(T, seed=9)

@@ -28,15 +28,15 @@ assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
 role_before = env.role.clone()
 env.rollout_random(1)
 torch.cuda.synchronize()
-s = buf.cpu().numpy()
-names = ["load+decode", "enumerate", "step", "(reset)", "requery", "count", "scan->end"]
+s = buf.cpu().numpy().astype(np.int64) if False else buf.cpu().numpy()
 import numpy as np
-d = np.diff(s[:, :7], axis=1).astype(np.float64)
-start = s[:, 0] - s[:, 0].min()
-print(f"T={T}: wave start spread: mean {start.mean():.0f} max {start.max():.0f} cycles")
-tot = (s[:, 6] - s[:, 0])
-print(f"per-wave total: mean {tot.mean():.0f}  p50 {np.median(tot):.0f}  p99 {np.percentile(tot,99):.0f}  max {tot.max():.0f}")
-print(f"kernel span (first start -> last end): {(s[:,6].max()-s[:,0].min())}")
-for k, nm in enumerate(names[:6]):
-    print(f"  {nm:12s} mean {d[:,k].mean():8.0f}  p99 {np.percentile(d[:,k],99):8.0f}  max {d[:,k].max():8.0f}")
-print(f"  {'scan->end':12s} mean {d[:,5+0].mean() if False else (s[:,6]-s[:,5]).mean():8.0f}  max {(s[:,6]-s[:,5]).max():8.0f}")
+names = ["prologue(entry->table)", "decode+philox", "scan(stage)", "flush rows", "pick+apply+store"]
+pts = np.stack([s[:, 7], s[:, 0], s[:, 1], s[:, 2], s[:, 3], s[:, 4]], axis=1).astype(np.float64)
+d = np.diff(pts, axis=1)
+tot = pts[:, -1] - pts[:, 0]
+print(f"T={T}: per-wave total: mean {tot.mean():.0f}  p50 {np.median(tot):.0f}  p99 {np.percentile(tot,99):.0f}  max {tot.max():.0f}")
+for k, nm in enumerate(names):
+    print(f"  {nm:24s} mean {d[:,k].mean():8.0f}  p50 {np.median(d[:,k]):8.0f}  p99 {np.percentile(d[:,k],99):8.0f}  max {d[:,k].max():8.0f}")
+cnt = env.counts.cpu().numpy()
+heavy = np.argsort(tot)[-5:]
+print("slowest waves: total / scan / apply / list size:", [(int(tot[h]), int(d[h,2]), int(d[h,4]), int(cnt[h])) for h in heavy])
