@@ -924,85 +924,112 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #ifdef DDZ_STAMP
     if (g_stamps && lane == 0) g_stamps[8 * t + 7] = t_entry;
 #endif
-    STAMP(0);
     uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
-    uint4 R = Rnext;
+    uint4 R = Rnext;  // lane f < 11 holds row f of the table for the whole launch
     if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
-    // the table's 11 rows stay in registers for all iterations of this launch; every
-    // iteration still stores its list, its state and its trajectory record to HBM
-    for (int64_t it = 0; it < a.n_iters; ++it) {
+    const uint64_t gid = a.gid_base + (uint64_t)t;
+    // decode once; afterwards the table's scalars are carried across the iterations
     const uint64_t P = pack_row(R);
     const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
+    const uint32_t mw = rl(R.w, DDZ_F_META), my_hi = my & 0xFFFF0000u;
     int role = mx & 0xFF;
     if (role > 2) role = 0;
-    const bool is_done = (mx >> 8) & 0xFF, dealt = (my >> 16) & 0xFF;
+    const bool active = ((my >> 16) & 0xFF) && !((mx >> 8) & 0xFF);  // dealt and not done
     uint32_t ply = my & 0xFFFF, episode = mz;
-    const uint64_t gid = a.gid_base + (uint64_t)t;
-    const bool active = dealt && !is_done;
-    const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
-    const uint64_t hand = rl64(P, DDZ_F_HAND0 + role);
-    const uint32_t info = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
-                                    rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
-    // the draw of this ply does not depend on the list: issue it before the scan
-    const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
-    const Out o{nullptr, nullptr, 0, 0, stage, sid};
-    Pick pk{-1, 0, 0, 0, 0};
-    STAMP(1);
-    int n = plan_scan<EM_STAGE, IDS>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
-    __builtin_amdgcn_wave_barrier();
-    if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
-      if (lane == 0) atomicOr(a.status, 2);
-      n = 0;
+    uint64_t h0 = rl64(P, DDZ_F_HAND0), h1 = rl64(P, DDZ_F_HAND0 + 1), h2 = rl64(P, DDZ_F_HAND0 + 2);
+    // the combo to beat (envi.py:103-109) as (trick, passes since it was played)
+    uint32_t trick = mk_info(EMPTY, 0, 1);
+    int passes = 0;
+    {
+      const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+      const uint64_t n1 = rl64(P, DDZ_F_RECENT0 + rm1), n2 = rl64(P, DDZ_F_RECENT0 + rp1);
+      if (n1) trick = info_of_row(n1, (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24));
+      else if (n2) { trick = info_of_row(n2, (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24)); passes = 1; }
     }
-    STAMP(2);
-    if (lane == 0) a.counts[t] = n;
-    s_rows += n;
-    const int64_t base = t * a.stride;
-    for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
-      const uint64_t e = stage[j];
-      a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
-      if (IDS) a.ids[base + j] = sid[j];
-    }
-    STAMP(3);
-    uint4 tr0 = make_uint4(0, 0, 0, 0);
-    uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)n & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
-    if (!active || n <= 0) {
-      tr1.x |= (uint32_t)is_done << 8 | 2u << 24;  // frozen table
-    } else {
-      const int idx = (int)__umulhi(rfl(d.x), (uint32_t)n);  // random.choice(actions), envi.py:83
-      const uint64_t e = stage[idx];
-      const uint4 c = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
-      const uint32_t c0 = rfl(c.x), c1 = rfl(c.y), c2 = rfl(c.z), c3 = rfl(c.w);
-      const uint32_t cw3 = c3 & 0x00FFFFFFu;
-      const uint32_t ncards = (uint32_t)nib_sum(e & 0x0FFFFFFFFFFFFFFFull);
-      if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
-        R.x -= c0; R.y -= c1; R.z -= c2; R.w -= cw3 + (ncards << 24);
-      } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
-        R.x += c0; R.y += c1; R.z += c2; R.w += cw3;
-      } else if (lane == DDZ_F_RECENT0 + role) {
-        R = make_uint4(c0, c1, c2, c3);
+    // engine RNG draws for 64 consecutive plies at once: lane j holds the draw of ply dbase + j
+    uint32_t draws = 0, dbase = 0, depi = 0;
+    bool dvalid = false;
+    for (int64_t it = 0; it < a.n_iters; ++it) {
+      STAMP(0);
+      uint4 tr0 = make_uint4(0, 0, 0, 0);
+      uint4 tr1 = make_uint4((uint32_t)role, ply << 16, episode, 0xFFFFFFFFu);
+      if (!active) {  // frozen table (never dealt / finished without auto-reset): empty list
+        if (lane == 0) a.counts[t] = 0;
+        tr1.x |= ((mx >> 8) & 0xFF) << 8 | 2u << 24;
+        if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
+        continue;
       }
-      const bool won = (rl(R.w, DDZ_F_HAND0 + role) >> 24) == 0;
-      const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
-      s_ply += 1; s_eps += won; s_lord += (won && role == 1);
-      tr0 = make_uint4(c0, c1, c2, c3);
-      tr1.x |= (uint32_t)won << 8 | o_reward << 16;
-      tr1.w = (uint32_t)idx;
-      ply += 1;
-      if (won) {  // auto-reset: next episode of this table
-        episode += 1;
-        uint64_t h0, h1, h2;
-        deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
-        R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
-            : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
-      } else if (lane == DDZ_F_META) {
-        R = make_uint4((uint32_t)rp1 | (0xFFu << 16), (my & 0xFFFF0000u) | (ply & 0xFFFF), mz, R.w);
+      if (!dvalid || depi != episode || ply - dbase >= 64u) {
+        dbase = ply; depi = episode; dvalid = true;
+        draws = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | (ply + (uint32_t)lane)), a.k0, a.k1).x;
       }
-      if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
-    }
-    if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
-    STAMP(4);
-    __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
+      const uint64_t hand = role == 0 ? h0 : role == 1 ? h1 : h2;
+      const uint32_t info = (passes >= 2) ? mk_info(EMPTY, 0, 1) : trick;
+      const Out o{nullptr, nullptr, 0, 0, stage, sid};
+      Pick pk{-1, 0, 0, 0, 0};
+      STAMP(1);
+      int n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
+      __builtin_amdgcn_wave_barrier();
+      if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
+        if (lane == 0) atomicOr(a.status, 2);
+        n = 0;
+      }
+      STAMP(2);
+      if (lane == 0) a.counts[t] = n;
+      s_rows += n;
+      const int64_t base = t * a.stride;
+      for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
+        const uint64_t e = stage[j];
+        a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
+        if (IDS) a.ids[base + j] = sid[j];
+      }
+      STAMP(3);
+      tr1.y |= (uint32_t)n & 0xFFFF;
+      if (n <= 0) {
+        tr1.x |= 2u << 24;
+      } else {
+        const int idx = (int)__umulhi(rl(draws, (int)(ply - dbase)), (uint32_t)n);  // random.choice, envi.py:83
+        const uint64_t e = stage[idx];                       // LDS broadcast read
+        const uint64_t anib = e & 0x0FFFFFFFFFFFFFFFull;
+        const uint32_t acat = (uint32_t)(e >> 60);
+        const uint4 c = unpack_row(anib, acat);              // the chosen row, same value in every lane
+        const uint32_t cw3 = c.w & 0x00FFFFFFu;
+        const uint32_t ncards = (uint32_t)nib_sum(anib);
+        if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
+          R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
+        } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
+          R.x += c.x; R.y += c.y; R.z += c.z; R.w += cw3;
+        } else if (lane == DDZ_F_RECENT0 + role) {
+          R = c;
+        }
+        // carried scalars
+        const uint64_t snib = (uint64_t)rfl((uint32_t)anib) | ((uint64_t)rfl((uint32_t)(anib >> 32)) << 32);
+        const uint32_t scat = rfl(acat);
+        const uint64_t hnew = hand - snib;
+        if (role == 0) h0 = hnew; else if (role == 1) h1 = hnew; else h2 = hnew;
+        if (snib) { trick = info_of_row(snib, (int)scat); passes = 0; } else { passes += 1; }
+        const bool won = hnew == 0;
+        const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
+        s_ply += 1; s_eps += won; s_lord += (won && role == 1);
+        tr0 = c;
+        tr1.x |= (uint32_t)won << 8 | o_reward << 16;
+        tr1.w = (uint32_t)idx;
+        ply += 1;
+        if (won) {  // auto-reset: next episode of this table
+          episode += 1;
+          deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
+          R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+              : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
+          role = 1; ply = 0; trick = mk_info(EMPTY, 0, 1); passes = 0;
+        } else {
+          role = role == 2 ? 0 : role + 1;  // lord -> down -> up, game.py:173-181
+          if (lane == DDZ_F_META) R = make_uint4((uint32_t)role | (0xFFu << 16), my_hi | (ply & 0xFFFF), episode, mw);
+        }
+        if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
+      }
+      if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
+      STAMP(4);
+      __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
     }
   }
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
