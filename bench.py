@@ -99,23 +99,26 @@ def main():
     assert st["plies"] == T * K and status == 0, (st, status)
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
-    # duration of the dominant kernel (all K iterations run inside one k_rollout launch): two
-    # HIP events around that launch on the launching stream; per-iteration share = launch / n
-    n_timed = min(K, 2000)
-    ms_table = env.rollout_random_timed(n_timed)
+    # duration of the dominant kernel: all iterations run inside ONE k_rollout launch; two HIP
+    # events around that launch on the launching stream (same workload, K iterations)
+    n_timed = K
+    ms_launch = env.rollout_random_timed(n_timed)
     s2 = env.stats()
-    mean_a2 = (s2["legal_rows"] - s1["legal_rows"]) / max(1, s2["plies"] - s1["plies"])
-    # algorithmic bytes per launch (DESIGN.md "Kernels"), per table:
-    #   in 176 B state rows; out 176 B state rows + 4 B list size + 16*A B legal rows
-    b_table = T * (356 + 16 * mean_a2)
-    dur_table = ms_table / n_timed * 1e-3
+    steps_timed = s2["plies"] - s1["plies"]
+    mean_a2 = (s2["legal_rows"] - s1["legal_rows"]) / max(1, steps_timed)
+    # algorithmic bytes per env step, SURVEY.md 8(d): 128 state read + 128 state write + 4 list
+    # size/offset + 16*A legal rows (DESIGN.md 3 states what the kernel really moves)
+    b_step = 260 + 16 * mean_a2
+    b_launch = b_step * steps_timed
+    dur_launch = ms_launch * 1e-3
     dominant = "k_rollout"
-    ach = b_table / dur_table / 1e9
+    ach = b_launch / dur_launch / 1e9
     traffic = None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(dominant, {}).get("hbm_bytes_per_launch")
+            per_step = json.load(open(tfile)).get(dominant, {}).get("hbm_bytes_per_env_step")
+            traffic = per_step * steps_timed if per_step is not None else None
         except Exception:
             traffic = None
 
@@ -132,8 +135,10 @@ def main():
                        "trajectory_gather": world > 1},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
-                         "us_per_launch": dur_table * 1e6,
-                         "algorithmic_bytes_per_launch": b_table},
+                         "launch_us": dur_launch * 1e6, "env_steps_per_launch": steps_timed,
+                         "us_per_iteration": dur_launch * 1e6 / n_timed,
+                         "algorithmic_bytes_per_env_step": b_step,
+                         "algorithmic_bytes_per_launch": b_launch},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)
