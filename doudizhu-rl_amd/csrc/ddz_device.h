@@ -56,10 +56,14 @@ __device__ __forceinline__ uint64_t pack_row(uint4 r) {  // byte 15 (aux) is dro
   uint64_t hi = (uint64_t)r.z | ((uint64_t)(r.w & 0x00FFFFFFu) << 32);
   return (uint64_t)squeeze8(lo) | ((uint64_t)squeeze8(hi) << 32);
 }
+__device__ __forceinline__ uint32_t spread4(uint32_t n16) {  // 4 nibbles -> 4 bytes
+  uint32_t w = (n16 | (n16 << 8)) & 0x00FF00FFu;
+  return (w | (w << 4)) & 0x0F0F0F0Fu;
+}
 __device__ __forceinline__ uint4 unpack_row(uint64_t nib, uint32_t aux) {
-  uint64_t lo = spread8((uint32_t)nib), hi = spread8((uint32_t)(nib >> 32));
-  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi,
-                    ((uint32_t)(hi >> 32) & 0x00FFFFFFu) | (aux << 24));
+  const uint32_t lo = (uint32_t)nib, hi = (uint32_t)(nib >> 32);
+  return make_uint4(spread4(lo & 0xFFFFu), spread4(lo >> 16), spread4(hi & 0xFFFFu),
+                    spread4((hi >> 16) & 0x0FFFu) | (aux << 24));
 }
 __device__ __forceinline__ int nib_sum(uint64_t nib) {  // number of cards
   uint64_t b = (nib & 0x0F0F0F0F0F0F0F0Full) + ((nib >> 4) & 0x0F0F0F0F0F0F0F0Full);

@@ -119,7 +119,8 @@ struct Out {
   uint4* rows;
   int32_t* ids;
   int64_t base, cap;
-  uint64_t* stage;      // EM_STAGE: per-wave LDS list of nib | category << 60, in id order
+  uint64_t* stage;      // EM_STAGE: per-wave LDS list of nib | category << 60, in id order,
+  uint16_t* stage_vl;   //           value | len << 8 of each entry (card.py:327-335)
   uint16_t* stage_ids;  //           and (IDS) the canonical ids
 };
 // what a scan does with the legal lanes
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
   }
   const uint32_t lut = c_line_lut.v[lane];
   const uint64_t deck = 0x0114444444444444ull;  // 4 of 3..2, one of each joker
-  Out o{g_tmp_rows, g_tmp_ids, 0, DDZ_NUM_ACTIONS, nullptr, nullptr};
+  Out o{g_tmp_rows, g_tmp_ids, 0, DDZ_NUM_ACTIONS, nullptr, nullptr, nullptr};
   Pick pk{-1, 0, 0, 0, 0};
   const int n = enumerate_table<true, false>(deck, mk_info(EMPTY, 0, 1), lut, lane, o, pk);
   __threadfence();
@@ -387,8 +388,8 @@ struct HotTab {
 
 // the action a lane is looking at, however its record was obtained
 template <int EM, bool IDS>
-__device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int cat, uint4 row, const Out& o, int n,
-                                         Pick& pk) {
+__device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int cat, int vl, uint4 row, const Out& o,
+                                         int n, Pick& pk) {
   const uint64_t b = __ballot(legal);
   const int k = __popcll(b);
   if (EM != EM_COUNT) {
@@ -396,6 +397,7 @@ __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int c
     if (EM == EM_STAGE) {
       if (legal && n + pre < STAGE_CAP) {
         o.stage[n + pre] = nib | ((uint64_t)cat << 60);
+        o.stage_vl[n + pre] = (uint16_t)vl;
         if (IDS) o.stage_ids[n + pre] = (uint16_t)id;
       }
     } else {
@@ -438,7 +440,7 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, u
     const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
     const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
                       (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
-    n = scan_emit<EM, IDS>(in && sub && gate, id, nib, cat, row, o, n, pk);
+    n = scan_emit<EM, IDS>(in && sub && gate, id, nib, cat, (int)(m.z & 0xFFFF), row, o, n, pk);
   }
   return n;
 }
@@ -465,7 +467,7 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
     }
     const bool sub = ((hand8 - nib) & H8) == H8;
     const uint4 row = ROWS ? unpack_row(nib, (uint32_t)cat) : make_uint4(0, 0, 0, 0);
-    n = scan_emit<EM, IDS>(in && sub, idb + j, nib, cat, row, o, n, pk);
+    n = scan_emit<EM, IDS>(in && sub, idb + j, nib, cat, s | (gap << 8), row, o, n, pk);
   }
   return n;
 }
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
         pk.want = (int)__umulhi(rfl(d.x), (uint32_t)cnt);
       }
-      const Out o{a.rows, a.ids, base, a.cap, nullptr, nullptr};
+      const Out o{a.rows, a.ids, base, a.cap, nullptr, nullptr, nullptr};
       const int n = plan_scan<PICK ? EM_PICK : EM_WRITE, IDS>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (n != cnt ? 1 : 0) | (base + cnt > a.cap ? 2 : 0);
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     }
     STAMP(4);
     if (COUNT) {
-      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr};
+      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
       Pick nopk{-1, 0, 0, 0, 0};
       const int c = (dealt && !is_done) ? plan_scan<EM_COUNT, false>(hand, info, hot, lane, none, nopk) : 0;
       if (lane == i) new_cnt_l = c;
@@ -905,6 +907,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #endif
   __shared__ HotTab hot;
   __shared__ uint64_t s_stage[WPB][STAGE_CAP];
+  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
   __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   hot_fill<TB>(hot);
   __syncthreads();
   uint64_t* stage = s_stage[wv];
+  uint16_t* svl = s_svl[wv];
   uint16_t* sid = s_sid[IDS ? wv : 0];
   int s_ply = 0, s_eps = 0, s_lord = 0;
   int64_t s_rows = 0;
@@ -949,6 +953,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     // engine RNG draws for 64 consecutive plies at once: lane j holds the draw of ply dbase + j
     uint32_t draws = 0, dbase = 0, depi = 0;
     bool dvalid = false;
+    uint4* tj = a.traj ? a.traj + 2 * t : nullptr;  // record of (iteration, table)
     for (int64_t it = 0; it < a.n_iters; ++it) {
       STAMP(0);
       uint4 tr0 = make_uint4(0, 0, 0, 0);
@@ -956,7 +961,8 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       if (!active) {  // frozen table (never dealt / finished without auto-reset): empty list
         if (lane == 0) a.counts[t] = 0;
         tr1.x |= ((mx >> 8) & 0xFF) << 8 | 2u << 24;
-        if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
+        if (tj && lane < 2) tj[lane] = lane == 0 ? tr0 : tr1;
+        if (tj) tj += 2 * a.T;
         continue;
       }
       if (!dvalid || depi != episode || ply - dbase >= 64u) {
@@ -965,7 +971,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       }
       const uint64_t hand = role == 0 ? h0 : role == 1 ? h1 : h2;
       const uint32_t info = (passes >= 2) ? mk_info(EMPTY, 0, 1) : trick;
-      const Out o{nullptr, nullptr, 0, 0, stage, sid};
+      const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
       Pick pk{-1, 0, 0, 0, 0};
       STAMP(1);
       int n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
@@ -1004,10 +1010,10 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         }
         // carried scalars
         const uint64_t snib = (uint64_t)rfl((uint32_t)anib) | ((uint64_t)rfl((uint32_t)(anib >> 32)) << 32);
-        const uint32_t scat = rfl(acat);
+        const uint32_t scat = rfl(acat), svlv = rfl((uint32_t)svl[idx]);
         const uint64_t hnew = hand - snib;
         if (role == 0) h0 = hnew; else if (role == 1) h1 = hnew; else h2 = hnew;
-        if (snib) { trick = info_of_row(snib, (int)scat); passes = 0; } else { passes += 1; }
+        if (snib) { trick = scat | (svlv << 8); passes = 0; } else { passes += 1; }
         const bool won = hnew == 0;
         const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
         s_ply += 1; s_eps += won; s_lord += (won && role == 1);
@@ -1027,7 +1033,8 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         }
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
       }
-      if (a.traj && lane < 2) a.traj[2 * (it * a.T + t) + lane] = lane == 0 ? tr0 : tr1;
+      if (tj && lane < 2) tj[lane] = lane == 0 ? tr0 : tr1;
+      if (tj) tj += 2 * a.T;
       STAMP(4);
       __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
     }
@@ -1075,7 +1082,7 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
     if (WRITE) {
       const int cnt = (int)rl((uint32_t)cnt_l, i);
       if (lane == 0) offsets[t] = (int32_t)base;
-      const Out o{rows, ids, base, cap, nullptr, nullptr};
+      const Out o{rows, ids, base, cap, nullptr, nullptr, nullptr};
       const int m = plan_scan<EM_WRITE, IDS>(hand, info, hot, lane, o, pk);
       if (lane == 0) {
         const int bits = (m != cnt ? 1 : 0) | (base + cnt > cap ? 2 : 0) | ((info & QF_BADLAST) ? 4 : 0);
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
       }
       base += cnt;
     } else {
-      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr};
+      const Out none{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
       const int c = plan_scan<EM_COUNT, false>(hand, info, hot, lane, none, pk);
       if (lane == i) new_cnt_l = c;
     }

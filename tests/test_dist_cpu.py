@@ -42,7 +42,13 @@ def _worker(rank, world, port, q):
         n, base = ddist.shard_tables(TOTAL, rank, world)
         local = torch.from_numpy(_rollout(n, base, seed=99))
         full = ddist.gather_trajectories(local)
-        q.put((rank, n, base, full.numpy()))
+        # gather to the learner rank, asynchronously, two half-batches in flight (bench.py's use)
+        half = ITERS // 2
+        h1 = ddist.gather_trajectories(local[:half].contiguous(), dst=0, async_op=True)
+        h2 = ddist.gather_trajectories(local[half:].contiguous(), dst=0, async_op=True)
+        a, b = h1.result(), h2.result()
+        to0 = None if a is None else torch.cat([a, b], dim=0).numpy()
+        q.put((rank, n, base, full.numpy(), to0))
     finally:
         dist.destroy_process_group()
 
@@ -73,9 +79,13 @@ def test_gather_trajectories_world2_matches_single_process():
         assert p.exitcode == 0
     assert [(r[1], r[2]) for r in res] == [(19, 0), (18, 19)]
     single = _rollout(TOTAL, 0, seed=99)
-    for _, _, _, full in res:                      # every rank holds the full batch, global id order
+    for rank, _, _, full, to0 in res:              # every rank holds the full batch, global id order
         assert full.shape == (ITERS, TOTAL, 32)
         assert np.array_equal(full, single)
+        if rank == 0:
+            assert np.array_equal(to0, single)     # dst=0: only the learner rank receives
+        else:
+            assert to0 is None
 
 
 def test_unpack_trajectory_fields():
