@@ -904,6 +904,15 @@ template <bool IDS>
 __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #ifdef DDZ_STAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t_last = t_entry;
+#define ACC(k)                                                       \
+  do {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    acc[k] += now_ - t_last;                                         \
+    t_last = now_;                                                   \
+  } while (0)
+#else
+#define ACC(k) do { } while (0)
 #endif
   __shared__ HotTab hot;
   __shared__ uint64_t s_stage[WPB][STAGE_CAP];
@@ -925,9 +934,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   int64_t s_rows = 0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
-#ifdef DDZ_STAMP
-    if (g_stamps && lane == 0) g_stamps[8 * t + 7] = t_entry;
-#endif
+    ACC(0);  // prologue (or previous table's tail)
     uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
     uint4 R = Rnext;  // lane f < 11 holds row f of the table for the whole launch
     if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
@@ -955,7 +962,6 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     bool dvalid = false;
     uint4* tj = a.traj ? a.traj + 2 * t : nullptr;  // record of (iteration, table)
     for (int64_t it = 0; it < a.n_iters; ++it) {
-      STAMP(0);
       uint4 tr0 = make_uint4(0, 0, 0, 0);
       uint4 tr1 = make_uint4((uint32_t)role, ply << 16, episode, 0xFFFFFFFFu);
       if (!active) {  // frozen table (never dealt / finished without auto-reset): empty list
@@ -973,14 +979,14 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       const uint32_t info = (passes >= 2) ? mk_info(EMPTY, 0, 1) : trick;
       const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
       Pick pk{-1, 0, 0, 0, 0};
-      STAMP(1);
+      ACC(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
       int n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
       __builtin_amdgcn_wave_barrier();
       if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
         if (lane == 0) atomicOr(a.status, 2);
         n = 0;
       }
-      STAMP(2);
+      ACC(2);  // scan (planner + rounds + staging)
       if (lane == 0) a.counts[t] = n;
       s_rows += n;
       const int64_t base = t * a.stride;
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
         if (IDS) a.ids[base + j] = sid[j];
       }
-      STAMP(3);
+      ACC(3);  // flush rows
       tr1.y |= (uint32_t)n & 0xFFFF;
       if (n <= 0) {
         tr1.x |= 2u << 24;
@@ -1035,10 +1041,14 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       }
       if (tj && lane < 2) tj[lane] = lane == 0 ? tr0 : tr1;
       if (tj) tj += 2 * a.T;
-      STAMP(4);
+      ACC(4);  // pick + apply + deal + state/trajectory stores
       __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
     }
   }
+#ifdef DDZ_STAMP
+  if (g_stamps && lane == 0 && ntab > 0)
+    for (int q = 0; q < 5; ++q) g_stamps[8 * t0 + q] = acc[q];
+#endif
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += s_lord; ws[3] += s_rows;

@@ -25,18 +25,15 @@ buf = torch.zeros((T, 8), dtype=torch.int64, device="cuda")
 raw = C.CDLL(lib)
 raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
 assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
-role_before = env.role.clone()
-env.rollout_random(1)
+N_IT = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+env.rollout_random(N_IT)
 torch.cuda.synchronize()
-s = buf.cpu().numpy().astype(np.int64) if False else buf.cpu().numpy()
 import numpy as np
-names = ["prologue(entry->table)", "decode+philox", "scan(stage)", "flush rows", "pick+apply+store"]
-pts = np.stack([s[:, 7], s[:, 0], s[:, 1], s[:, 2], s[:, 3], s[:, 4]], axis=1).astype(np.float64)
-d = np.diff(pts, axis=1)
-tot = pts[:, -1] - pts[:, 0]
-print(f"T={T}: per-wave total: mean {tot.mean():.0f}  p50 {np.median(tot):.0f}  p99 {np.percentile(tot,99):.0f}  max {tot.max():.0f}")
+s = buf.cpu().numpy().astype(np.float64)
+names = ["prologue", "iter setup", "scan", "flush", "pick+apply+stores"]
+tot = s[:, :5].sum(1)
+print(f"T={T}, {N_IT} in-launch iterations; cycles per wave per iteration (s_memtime):")
+print(f"  total/iter  mean {tot.mean()/N_IT:8.0f}  max {tot.max()/N_IT:8.0f}")
 for k, nm in enumerate(names):
-    print(f"  {nm:24s} mean {d[:,k].mean():8.0f}  p50 {np.median(d[:,k]):8.0f}  p99 {np.percentile(d[:,k],99):8.0f}  max {d[:,k].max():8.0f}")
-cnt = env.counts.cpu().numpy()
-heavy = np.argsort(tot)[-5:]
-print("slowest waves: total / scan / apply / list size:", [(int(tot[h]), int(d[h,2]), int(d[h,4]), int(cnt[h])) for h in heavy])
+    per = s[:, k] / (1 if k == 0 else N_IT)
+    print(f"  {nm:20s} mean {per.mean():8.0f}  p99 {np.percentile(per,99):8.0f}  max {per.max():8.0f}" + ("  (once per launch)" if k == 0 else ""))
