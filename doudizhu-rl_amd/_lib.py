@@ -35,6 +35,7 @@ SYMBOLS = {
     "ddz_rollout_random_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -1,17 +1,11 @@
-"""Constants of the reference's config.py:8-18, copied by value (the reference module also
-creates log directories and imports pytz at import time, which the hot path does not need)."""
+"""The two module-level names of the reference's config.py that the env adapter reads
+(config.py:16-20): the rank -> label map used by cards2str, and the default torch device.
+The DQN hyper-parameters, directories and logger of that module belong to the training
+scripts, which are outside this package."""
 import torch
 
-GAMMA = 0.95
-EPSILON_HIGH = 0.5
-EPSILON_LOW = 0.01
-REPLAY_SIZE = 20000
-BATCH_SIZE = 256
-DECAY = int((8000 * (2 / 3)) / 5)
-UPDATE_TARGET_EVERY = 20
-
-CARDS = range(3, 18)
-STR = [str(i) for i in range(3, 11)] + ['J', 'Q', 'K', 'A', '2', '小', '大']
-DICT = dict(zip(CARDS, STR))
+# ranks 3..17 = 3..10, J, Q, K, A, 2, small joker, big joker (envi.py:122-124)
+_FACES = {11: 'J', 12: 'Q', 13: 'K', 14: 'A', 15: '2', 16: '小', 17: '大'}
+DICT = {rank: _FACES.get(rank, str(rank)) for rank in range(3, 18)}
 
 DEVICE = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")

@@ -1126,6 +1126,36 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
   }
 }
 
+// action selection of DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71) for every table:
+// choice = first index of the maximum q of the table's CSR segment (torch.argmax, dqn.py:60,70);
+// with probability epsilon (engine RNG domain 3, one Philox call per table and ply) a uniform
+// index instead (dqn.py:57-58).  thr = floor(epsilon * 2^32): explore <=> draw.x < thr.
+__global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ state, int64_t T, uint32_t k0, uint32_t k1,
+                                                  uint64_t gid_base, const float* __restrict__ q,
+                                                  const int32_t* __restrict__ offsets, uint64_t thr,
+                                                  int32_t* __restrict__ choice) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= T) return;
+  const int32_t off = offsets[t], A = offsets[t + 1] - off;
+  if (A <= 0) {
+    choice[t] = -1;
+    return;
+  }
+  int best = 0;
+  float bq = q[off];
+  for (int j = 1; j < A; ++j) {
+    const float v = q[off + j];
+    if (v > bq) { bq = v; best = j; }
+  }
+  if (thr) {
+    const uint4 meta = *(const uint4*)(state + t * STATE_ROW_BYTES + DDZ_F_META * 16);
+    const uint64_t gid = gid_base + (uint64_t)t;
+    const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), meta.z, (3u << 16) | (meta.y & 0xFFFF)), k0, k1);
+    if ((uint64_t)d.x < thr) best = (int)__umulhi(d.y, (uint32_t)A);
+  }
+  choice[t] = best;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ rows, int64_t n,
                                                     uint32_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1573,6 +1603,18 @@ int ddz_debug_set_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : DDZ_EHIP;
 }
 #endif
+
+int ddz_select(ddz_env_t* e, const float* q, const int32_t* offsets, double epsilon, int32_t* choice, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!q || !offsets || !choice || !(epsilon >= 0.0) || epsilon > 1.0) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  const uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q, offsets,
+                     thr, choice);
+  return check_launch();
+}
 
 // debug/test entry: classify(rows) -> info words (category | value << 8 | len << 16, 0xFF invalid)
 int ddz_debug_classify(int device, const int8_t* rows, int64_t n, uint32_t* out, void* stream) {

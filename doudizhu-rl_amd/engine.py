@@ -157,6 +157,17 @@ class BatchedEnv:
         check(self.lib.ddz_observe(self._h, int(variant), _p(out), _stream(self.device)))
         return out
 
+    def select(self, q, epsilon=0.0, out=None):
+        """greedy / epsilon-greedy choice per table from per-row values q (f32, CSR order of
+        the current legal list; dqn.py:50-71).  Returns int32[T] indices for step(STEP_CHOICE)."""
+        self._need_legal()
+        q = q.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
+        if out is None:
+            out = torch.empty(self.T, dtype=torch.int32, device=self.device)
+        check(self.lib.ddz_select(self._h, _p(q), _p(self.offsets), float(epsilon), _p(out),
+                                  _stream(self.device)))
+        return out
+
     def legal_onehot(self):
         """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
         self._need_legal()

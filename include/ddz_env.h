@@ -142,6 +142,14 @@ int ddz_rollout_random_timed(ddz_env_t* env, int64_t n_iters, int32_t* counts, i
  * ddz_step / ddz_legal since the last read; the internal accumulators are cleared.        */
 int ddz_read_stats(ddz_env_t* env, int64_t* stats, void* stream);
 
+/* Replaces the action selection of DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71)
+ * for all tables: q float[offsets[T]] holds one value per legal row in CSR order;
+ * choice int32[T] = first index of the segment's maximum (torch.argmax, dqn.py:60,70), -1 for
+ * an empty list.  With epsilon > 0 a table explores with that probability (engine RNG
+ * domain 3, keyed by table id / episode / ply): uniform index (dqn.py:57-58).             */
+int ddz_select(ddz_env_t* env, const float* q, const int32_t* offsets, double epsilon,
+               int32_t* choice, void* stream);
+
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */
 int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);

@@ -475,6 +475,31 @@ void ddzo_env_observe(const uint8_t* s, int64_t T, int variant, float* out) {
   }
 }
 
+/* DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71): first index of the maximum;
+ * exploration by the engine RNG, domain 3 (spec v1): draw.x < floor(eps * 2^32) -> uniform */
+void ddzo_select(const uint8_t* s, int64_t T, uint64_t seed, uint64_t gid_base, const float* q,
+                 const int32_t* offsets, double epsilon, int32_t* choice) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
+  for (int64_t t = 0; t < T; ++t) {
+    int32_t off = offsets[t], A = offsets[t + 1] - off;
+    if (A <= 0) { choice[t] = -1; continue; }
+    int best = 0;
+    for (int j = 1; j < A; ++j)
+      if (q[off + j] > q[off + best]) best = j;
+    if (thr) {
+      const uint8_t* m = cfld(s, T, DDZO_F_META, t);
+      uint64_t gid = gid_base + (uint64_t)t;
+      uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), rd32(m + DDZO_M_EPISODE),
+                         (3u << 16) | rd16(m + DDZO_M_PLY)};
+      uint32_t out[4];
+      ddzo_philox4x32_10(ctr, key, out);
+      if ((uint64_t)out[0] < thr) best = (int)(((uint64_t)out[1] * (uint32_t)A) >> 32);
+    }
+    choice[t] = best;
+  }
+}
+
 int64_t ddzo_rollout_random(uint8_t* s, int64_t T, uint64_t seed, uint64_t gid_base,
                             int64_t n_iters, int64_t* sum_legal, int64_t* episodes_done) {
   ddzo_init();

@@ -56,6 +56,7 @@ def lib():
         L.ddzo_planes.restype = C.c_int
         L.ddzo_env_observe.argtypes = [p, C.c_int64, C.c_int, p]
         L.ddzo_rows_to_onehot.argtypes = [p, C.c_int64, p]
+        L.ddzo_select.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, p, p, C.c_double, p]
         L.ddzo_rollout_random.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, p, p]
         L.ddzo_rollout_random.restype = C.c_int64
         L.ddzo_init()
@@ -146,6 +147,13 @@ class OracleEnv:
     def observe(self, variant):
         out = np.zeros((self.T, PLANES[variant], 15, 4), np.float32)
         lib().ddzo_env_observe(_ptr(self.state), self.T, variant, _ptr(out))
+        return out
+
+    def select(self, q, epsilon=0.0):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros(self.T, np.int32)
+        lib().ddzo_select(_ptr(self.state), self.T, self.seed, self.gid_base, _ptr(q), _ptr(self.offsets),
+                          float(epsilon), _ptr(out))
         return out
 
     def rollout_random(self, n_iters):

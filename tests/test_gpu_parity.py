@@ -286,6 +286,36 @@ def test_full_size_properties(pkg, T):
     assert (idv >= 0).all() and (idv < NA).all()
 
 
+@pytest.mark.parametrize("eps", [0.0, 0.3, 1.0])
+def test_select_matches_argmax_and_oracle(pkg, oracle, eps):
+    """greedy / epsilon-greedy selection (dqn.py:50-71) over the CSR list, then a CHOICE step."""
+    T = 3000
+    env = pkg.BatchedEnv(T, seed=12)
+    ref = oracle.OracleEnv(T, seed=12)
+    env.reset(); ref.reset()
+    g = torch.Generator().manual_seed(1)
+    explored = 0
+    for it in range(25):
+        offsets, rows, ids = env.legal()
+        roff, _, _ = ref.legal()
+        n = int(roff[-1])
+        q = torch.randint(-3, 4, (n,), generator=g).float()      # many ties: argmax must take the first
+        choice = env.select(q.to(_dev()), eps)
+        want = ref.select(q.numpy(), eps)
+        assert np.array_equal(choice.cpu().numpy(), want)
+        if eps == 0.0:
+            seg = np.repeat(np.arange(T), np.diff(roff))
+            first = np.array([int(torch.argmax(q[roff[t]:roff[t + 1]])) for t in range(0, T, 37)])
+            assert np.array_equal(want[::37], first)              # torch.argmax semantics (dqn.py:60)
+        else:
+            greedy = ref.select(q.numpy(), 0.0)
+            explored += int((want != greedy).sum())
+        env.step(choice, pkg.STEP_CHOICE); ref.step(oracle.STEP_CHOICE, want)
+        assert np.array_equal(env.state.cpu().numpy(), ref.state)
+    if eps > 0:
+        assert explored > 0
+
+
 def test_state_export_import_and_determinism(pkg):
     env = pkg.BatchedEnv(2048, seed=5)
     env.reset()
