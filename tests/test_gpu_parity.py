@@ -169,6 +169,26 @@ def test_rollout_slabs_vs_oracle(pkg, oracle, T, iters, seed, base):
     assert s["plies"] == T * it and s["legal_rows"] > 0
 
 
+@pytest.mark.parametrize("T", [1, 7, 9, 513])
+def test_ragged_table_counts(pkg, oracle, T):
+    """table counts that do not fill a block / a wave group: CSR path and rollout path"""
+    env = pkg.BatchedEnv(T, seed=6, table_id_base=2 ** 40 + 5)
+    env2 = pkg.BatchedEnv(T, seed=6, table_id_base=2 ** 40 + 5)
+    ref = oracle.OracleEnv(T, seed=6, gid_base=2 ** 40 + 5)
+    env.reset(); env2.reset(); ref.reset()
+    for it in range(70):
+        offsets, rows, ids = env.legal()
+        roff, rrows, rids = ref.legal()
+        n = int(roff[-1])
+        assert np.array_equal(offsets.cpu().numpy(), roff)
+        assert np.array_equal(rows[:n].cpu().numpy(), rrows) and np.array_equal(ids[:n].cpu().numpy(), rids)
+        env.step_random(); ref.step(oracle.STEP_RANDOM)
+        assert np.array_equal(env.state.cpu().numpy(), ref.state)
+    env2.rollout_random(70)
+    assert np.array_equal(env2.state.cpu().numpy(), ref.state)
+    assert env.status() == 0 and env2.status() == 0
+
+
 def test_no_auto_reset_freezes_tables(pkg, oracle):
     T = 512
     env = pkg.BatchedEnv(T, seed=9)
