@@ -138,6 +138,15 @@ def main():
         except Exception:
             traffic = None
 
+    # the same loop with packed CSR lists (one launch per iteration): reported, not the headline
+    n_csr = min(K, 500)
+    env.rollout_random_csr(20)
+    torch.cuda.synchronize(dev)
+    tc = time.perf_counter()
+    env.rollout_random_csr(n_csr)
+    torch.cuda.synchronize(dev)
+    csr_rate = T * n_csr / (time.perf_counter() - tc)
+
     if rank == 0:
         out = {
             "metric": "env steps/sec (batched tables)", "value": total_tables * K / dt,
@@ -148,6 +157,8 @@ def main():
                                    "only (no NN), auto-reset; BASELINE.json configs[1]",
                        "tables_per_gpu": T, "total_tables": total_tables,
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
+                       "list_layout": "slab (fixed-stride segment per table); packed-CSR variant of the "
+                                      "same loop: %.4g env steps/s per GPU" % csr_rate,
                        "trajectory_gather": world > 1},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,

@@ -32,6 +32,8 @@ SYMBOLS = {
                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddz_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_rollout_random_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_rollout_random_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1561,6 +1561,27 @@ int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* r
   return DDZ_OK;
 }
 
+int ddz_rollout_random_csr(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap,
+                           uint8_t* traj, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (n_iters < 0 || !offsets || !rows || cap < 0) return DDZ_EINVAL;
+  if (cap > 0x7FFFFFFF) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  e->legal_cap = cap;
+  Io io;
+  io.offsets = offsets; io.rows = rows; io.ids = ids; io.cap = cap; io.auto_reset = 1;
+  for (int64_t it = 0; it < n_iters; ++it) {
+    int rc = ensure_counts(e, st);
+    if (rc) return rc;
+    io.traj = traj ? traj + it * e->T * DDZ_TRAJ_BYTES : nullptr;
+    rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);  // CSR needs the scan of the previous launch
+    if (rc) return rc;
+  }
+  return DDZ_OK;
+}
+
 int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids,
                              int64_t stride, double* ms, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;

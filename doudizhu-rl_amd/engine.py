@@ -204,6 +204,17 @@ class BatchedEnv:
                                           _stream(self.device)))
         self._legal_fresh = False
 
+    def rollout_random_csr(self, n_iters, traj=None):
+        """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them); one
+        launch per iteration because CSR bases depend on every table.  Same states and
+        trajectories as rollout_random."""
+        if traj is not None and (traj.dtype != torch.uint8 or not traj.is_contiguous()
+                                 or traj.numel() != n_iters * self.T * TRAJ_BYTES):
+            raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
+        check(self.lib.ddz_rollout_random_csr(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
+                                              _p(self.ids), self.cap, _p(traj), _stream(self.device)))
+        self._legal_fresh = False
+
     def rollout_random_timed(self, n_iters):
         """Same loop between two hipEvents; returns the elapsed ms of the n_iters launches.
         Synchronises; measurement aid for bench.py."""

@@ -132,6 +132,14 @@ int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t*
                        int32_t* ids, int64_t stride, int64_t* stats, uint8_t* traj,
                        void* stream);
 
+/* The same random-policy loop with the lists in the CSR layout of ddz_legal (offsets/rows/ids
+ * packed across tables).  CSR bases need a scan over all tables, so this variant is one
+ * launch per iteration: the fused kernel writes the list of the current state, steps, and
+ * sizes + scans the lists of the new state for the next launch.  Same trajectories, same
+ * states as ddz_rollout_random; after the call offsets/rows hold the last pre-step lists.     */
+int ddz_rollout_random_csr(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
+                           int32_t* ids, int64_t row_capacity, uint8_t* traj, void* stream);
+
 /* Measurement aid: the same loop between two hipEvents on `stream`.  ms (HOST, double[2])
  * receives {elapsed ms of the launch, n_iters}; synchronises the stream.
  * Used by bench.py for the roofline figure.                                                */

@@ -189,6 +189,26 @@ def test_ragged_table_counts(pkg, oracle, T):
     assert env.status() == 0 and env2.status() == 0
 
 
+def test_rollout_csr_equals_slab_rollout(pkg, oracle):
+    """the CSR-list variant of the fused rollout: same trajectories and states as the slab one,
+    and its last lists are the oracle's CSR lists"""
+    T, n = 1500, 60
+    a = pkg.BatchedEnv(T, seed=31); b = pkg.BatchedEnv(T, seed=31); ref = oracle.OracleEnv(T, seed=31)
+    a.reset(); b.reset(); ref.reset()
+    ta = torch.zeros((n, T, 32), dtype=torch.uint8, device=_dev()); tb = torch.zeros_like(ta)
+    a.rollout_random(n, traj=ta)
+    b.rollout_random_csr(n, traj=tb)
+    assert torch.equal(ta, tb) and torch.equal(a.state, b.state)
+    for _ in range(n - 1):
+        ref.legal(); ref.step(oracle.STEP_RANDOM)
+    roff, rrows, rids = ref.legal()
+    ref.step(oracle.STEP_RANDOM)
+    m = int(roff[-1])
+    assert np.array_equal(b.offsets.cpu().numpy(), roff)
+    assert np.array_equal(b.rows[:m].cpu().numpy(), rrows) and np.array_equal(b.ids[:m].cpu().numpy(), rids)
+    assert np.array_equal(b.state.cpu().numpy(), ref.state) and b.status() == 0
+
+
 def test_no_auto_reset_freezes_tables(pkg, oracle):
     T = 512
     env = pkg.BatchedEnv(T, seed=9)
