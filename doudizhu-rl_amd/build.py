@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libddz_hip.so")
 SOURCES = ["ddz_engine.hip"]
-DEPS = ["ddz_device.h", os.path.join("..", "..", "include", "ddz_env.h")]
+DEPS = ["ddz_device.h", "ddz_build_table.h", os.path.join("..", "..", "include", "ddz_env.h")]
 
 
 def hipcc():

@@ -3,9 +3,8 @@
 // Representation: a card-count vector (ranks 3..K,A,2,BJ,CJ; envi.py:122-124) lives in
 // HBM as a 16-byte row (int8 counts[15] + 1 aux byte) and in registers as a
 // nibble-packed u64 ("nib"): rank i at bits [4i, 4i+4).  All rule predicates are SWAR
-// arithmetic on nibs or bit tests on 15-bit rank masks; there is no table of the
-// 13,527 actions on the device -- action ids are computed in closed form from the
-// layout of rule_based/utils/card.py:34-159 (reference paths relative to /root/reference).
+// arithmetic on nibs or bit tests on 15-bit rank masks.  Canonical action ids follow the
+// order of rule_based/utils/card.py:34-159 (reference paths relative to /root/reference).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -85,18 +84,6 @@ __device__ __forceinline__ uint64_t spread15(uint32_t m) {  // bit r -> bit 4r
   x = (x | (x << 6)) & 0x0303030303030303ull;
   x = (x | (x << 3)) & ONES;
   return x;
-}
-
-struct Masks {  // m_k = ranks held at least k times
-  uint32_t m1, m2, m3, m4;
-};
-__device__ __forceinline__ Masks masks_of(uint64_t nib) {
-  Masks m;
-  m.m1 = ge_mask(nib, 1);
-  m.m2 = ge_mask(nib, 2) & M13;
-  m.m3 = ge_mask(nib, 3) & M13;
-  m.m4 = ge_mask(nib, 4) & M13;
-  return m;
 }
 
 __device__ __forceinline__ uint32_t gt_mask(int v) {  // ranks strictly above v (v may be 100)
