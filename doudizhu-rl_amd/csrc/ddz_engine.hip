@@ -65,7 +65,7 @@ struct Scratch {  // device pointers into the scratch buffer
   int32_t* counts[2];    // size of each table's legal list (ping-pong)
   int32_t* local_off[2]; // exclusive scan of counts inside the table's block
   int32_t* blk_tot[2];   // sum of counts per block
-  int64_t* blk_stats;    // [T][4] per block / per wave: plies, episodes, lord wins, rows
+  int64_t* blk_stats;    // [T][4] per block / per wave: plies, episodes, lord wins | up wins << 32, rows
   int32_t* status;       // [0] status bits
   int64_t* legal_rows;   // running total of rows produced
 };
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   int64_t base = 0;
   int cnt_l = 0;      // lane i: size of the current list of table t0 + i
   int new_cnt_l = 0;  // lane i: size of the next list of table t0 + i
-  int s_ply = 0, s_eps = 0, s_lord = 0;
+  int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
   // all independent global loads of the prologue are issued before anything waits
   int part = 0, loc0 = 0;
   uint4 Rnext = make_uint4(0, 0, 0, 0);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         const bool won = (rl(R.w, DDZ_F_HAND0 + role) >> 24) == 0;
         o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14: -1 lord won, +1 farmers
         o_done = won;
-        s_ply += 1; s_eps += won; s_lord += (won && role == 1);
+        s_ply += 1; s_eps += won; s_lord += (won && role == 1); s_up += (won && role == 0);
         tr0 = make_uint4(c0, c1, c2, c3);
         tr1.x |= (uint32_t)won << 8 | o_reward << 16;
         tr1.w = (uint32_t)idx;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     __shared__ int sh[WPB][4];
     const int incl = wave_incl_scan(new_cnt_l, lane);
     if (lane == 63) {
-      sh[wv][0] = incl; sh[wv][1] = s_ply; sh[wv][2] = s_eps; sh[wv][3] = s_lord;
+      sh[wv][0] = incl; sh[wv][1] = s_ply; sh[wv][2] = s_eps; sh[wv][3] = s_lord | (s_up << 16);
     }
     __syncthreads();
     int wbase = 0, tot = 0;
@@ -671,9 +671,9 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       a.nxt_blk[blockIdx.x] = tot;
       if (STEP) {
         int64_t* bs = a.blk_stats + 4 * (int64_t)blockIdx.x;
-        int p = 0, e = 0, l = 0;
-        for (int w = 0; w < WPB; ++w) { p += sh[w][1]; e += sh[w][2]; l += sh[w][3]; }
-        bs[0] += p; bs[1] += e; bs[2] += l;
+        int p = 0, e = 0, l = 0, u = 0;
+        for (int w = 0; w < WPB; ++w) { p += sh[w][1]; e += sh[w][2]; l += sh[w][3] & 0xFFFF; u += sh[w][3] >> 16; }
+        bs[0] += p; bs[1] += e; bs[2] += (int64_t)l | ((int64_t)u << 32);
       }
     }
   }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   uint64_t* stage = s_stage[wv];
   uint16_t* svl = s_svl[wv];
   uint16_t* sid = s_sid[IDS ? wv : 0];
-  int s_ply = 0, s_eps = 0, s_lord = 0;
+  int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
   int64_t s_rows = 0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         if (snib) { trick = scat | (svlv << 8); passes = 0; } else { passes += 1; }
         const bool won = hnew == 0;
         const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
-        s_ply += 1; s_eps += won; s_lord += (won && role == 1);
+        s_ply += 1; s_eps += won; s_lord += (won && role == 1); s_up += (won && role == 0);
         tr0 = c;
         tr1.x |= (uint32_t)won << 8 | o_reward << 16;
         tr1.w = (uint32_t)idx;
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #endif
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
     int64_t* ws = a.wave_stats + 4 * wave;
-    ws[0] += s_ply; ws[1] += s_eps; ws[2] += s_lord; ws[3] += s_rows;
+    ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
   }
 }
 
@@ -966,20 +966,21 @@ __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ ro
   if (t < n) out[t] = classify(pack_row(rows[t]));
 }
 
-// stats[0..3] += {plies, episodes, legal rows, lord wins}; the slots are cleared
+// stats[0..5] += {plies, episodes, legal rows, lord wins, up wins, down wins}; slots are cleared
 __global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nslots, int64_t* stats) {
-  __shared__ long long sh[4][BLOCK];
-  long long v[4] = {0, 0, 0, 0};
-  for (int64_t b = threadIdx.x; b < nslots; b += BLOCK)
-    for (int k = 0; k < 4; ++k) {
-      v[k] += sc.blk_stats[4 * b + k];
-      sc.blk_stats[4 * b + k] = 0;
-    }
-  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = v[k];
+  __shared__ long long sh[5][BLOCK];
+  long long v[5] = {0, 0, 0, 0, 0};  // plies, episodes, lord wins, rows, up wins
+  for (int64_t b = threadIdx.x; b < nslots; b += BLOCK) {
+    const long long w = sc.blk_stats[4 * b + 2];
+    v[0] += sc.blk_stats[4 * b]; v[1] += sc.blk_stats[4 * b + 1]; v[3] += sc.blk_stats[4 * b + 3];
+    v[2] += w & 0xFFFFFFFFll; v[4] += w >> 32;
+    for (int k = 0; k < 4; ++k) sc.blk_stats[4 * b + k] = 0;
+  }
+  for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
   for (int d = BLOCK / 2; d > 0; d >>= 1) {
     if ((int)threadIdx.x < d)
-      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
+      for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + d];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -987,6 +988,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nslo
     stats[1] += sh[1][0];
     stats[2] += *sc.legal_rows + sh[3][0];
     stats[3] += sh[2][0];
+    stats[4] += sh[4][0];
+    stats[5] += sh[1][0] - sh[2][0] - sh[4][0];
     *sc.legal_rows = 0;
   }
 }

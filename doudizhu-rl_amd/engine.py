@@ -67,7 +67,7 @@ class BatchedEnv:
         self.done = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
-        self._stats = torch.zeros(4, dtype=torch.int64, device=d)
+        self._stats = torch.zeros(8, dtype=torch.int64, device=d)
         self._legal_fresh = False
         h = C.c_void_p()
         check(self.lib.ddz_create(C.byref(h), self.T, self.seed, self.table_id_base, d.index,
@@ -226,10 +226,11 @@ class BatchedEnv:
         return ms[0]
 
     def stats(self):
-        """{plies, episodes, legal_rows, lord_wins} accumulated so far (host sync)."""
+        """{plies, episodes, legal_rows, lord_wins, up_wins, down_wins} accumulated so far (the
+        per-role win counts of Game.compete, game.py:258-290); host sync."""
         check(self.lib.ddz_read_stats(self._h, _p(self._stats), _stream(self.device)))
-        p, e, l, w = self._stats.tolist()
-        return {"plies": p, "episodes": e, "legal_rows": l, "lord_wins": w}
+        p, e, l, w, u, dn = self._stats.tolist()[:6]
+        return {"plies": p, "episodes": e, "legal_rows": l, "lord_wins": w, "up_wins": u, "down_wins": dn}
 
     def status(self):
         """device status word (0 = healthy); host sync."""

@@ -126,8 +126,9 @@ int ddz_get_moves(int device_id, const int8_t* hands, const int8_t* lasts, int64
  * counts/rows hold the lists of the last pre-step states).
  *   counts int32[T]; rows int8[T * stride][16]; ids int32[T * stride] or NULL;
  *   stride >= 512 covers every list of a <= 20-card hand (497 is the maximum);
- *   stats (device, int64[4], may be NULL) accumulates {plies, finished episodes, total legal
- *   rows, lord wins}; traj (may be NULL) is u8[n_iters][T][32].                            */
+ *   stats (device, int64[8], may be NULL) accumulates {plies, finished episodes, total legal
+ *   rows, lord wins, up wins, down wins, -, -} (Game.compete's per-role win counts,
+ *   game.py:258-290); traj (may be NULL) is u8[n_iters][T][32].                            */
 int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t* rows,
                        int32_t* ids, int64_t stride, int64_t* stats, uint8_t* traj,
                        void* stream);
@@ -146,8 +147,9 @@ int ddz_rollout_random_csr(ddz_env_t* env, int64_t n_iters, int32_t* offsets, in
 int ddz_rollout_random_timed(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t* rows,
                              int32_t* ids, int64_t stride, double* ms, void* stream);
 
-/* stats (device, int64[4]) += {plies, finished episodes, legal rows, lord wins} accumulated by
- * ddz_step / ddz_legal since the last read; the internal accumulators are cleared.        */
+/* stats (device, int64[8]) += {plies, finished episodes, legal rows, lord wins, up wins, down
+ * wins, -, -} accumulated by ddz_step / ddz_legal / the rollouts since the last read; the
+ * internal accumulators are cleared.                                                      */
 int ddz_read_stats(ddz_env_t* env, int64_t* stats, void* stream);
 
 /* Replaces the action selection of DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71)

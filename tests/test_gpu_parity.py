@@ -167,6 +167,25 @@ def test_rollout_slabs_vs_oracle(pkg, oracle, T, iters, seed, base):
     assert env.status() == 0
     s = env.stats()
     assert s["plies"] == T * it and s["legal_rows"] > 0
+    assert s["lord_wins"] + s["up_wins"] + s["down_wins"] == s["episodes"]
+    assert min(s["lord_wins"], s["up_wins"], s["down_wins"]) > 0 or T < 100
+
+
+def test_win_counts_match_trajectories(pkg):
+    """stats (Game.compete's per-role wins, game.py:258-290) against the trajectory records,
+    for both rollout variants"""
+    T, n = 2000, 150
+    for variant in ("slab", "csr"):
+        env = pkg.BatchedEnv(T, seed=17)
+        env.reset()
+        traj = torch.zeros((n, T, 32), dtype=torch.uint8, device=_dev())
+        (env.rollout_random if variant == "slab" else env.rollout_random_csr)(n, traj=traj)
+        tr = traj.cpu().numpy()
+        done, role = tr[..., 17] == 1, tr[..., 16]
+        s = env.stats()
+        assert s["episodes"] == done.sum() > 3000
+        assert [s["up_wins"], s["lord_wins"], s["down_wins"]] == [int((done & (role == r)).sum()) for r in range(3)]
+        assert s["plies"] == T * n
 
 
 @pytest.mark.parametrize("T", [1, 7, 9, 513])
