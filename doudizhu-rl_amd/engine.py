@@ -146,6 +146,17 @@ class BatchedEnv:
         self._legal_fresh = False
         return self.done, self.reward, self.illegal
 
+    def step_onehot(self, actions, auto_reset=True, traj=None):
+        """step_manual with the reference's action encoding (envi.py:63-70): actions f32/int
+        [T,15,4] thermometers (what valid_actions(tensor=True) rows look like); decoded on the
+        device by the row sum of onehot2arr (envi.py:148-157)."""
+        a = actions.to(self.device)
+        if tuple(a.shape) != (self.T, 15, 4):
+            raise ValueError("actions must be [T,15,4]")
+        rows = torch.zeros((self.T, ROW), dtype=torch.int8, device=self.device)
+        rows[:, :15] = a.sum(dim=2).round().to(torch.int8)
+        return self.step(rows, STEP_ROWS, auto_reset, traj)
+
     def step_random(self, auto_reset=True, traj=None):
         return self.step(None, STEP_RANDOM, auto_reset, traj)
 

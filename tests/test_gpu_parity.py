@@ -375,6 +375,25 @@ def test_select_matches_argmax_and_oracle(pkg, oracle, eps):
         assert explored > 0
 
 
+def test_step_onehot_matches_step_choice(pkg):
+    """batched step_manual with [T,15,4] thermometer actions == stepping by list index"""
+    T = 1024
+    a = pkg.BatchedEnv(T, seed=23); b = pkg.BatchedEnv(T, seed=23)
+    a.reset(); b.reset()
+    g = torch.Generator().manual_seed(3)
+    for _ in range(40):
+        offsets, rows, _ = a.legal()
+        b.legal()
+        A = offsets.diff().cpu()
+        choice = (torch.randint(0, 1 << 30, (T,), generator=g) % A.clamp(min=1)).int()
+        picked = rows[(offsets[:-1].cpu().long() + choice.long()).to(rows.device)]
+        onehot = pkg.rows_to_onehot(picked)                     # [T,15,4] f32, as valid_actions gives
+        d1, r1, i1 = a.step(choice, pkg.STEP_CHOICE)
+        d2, r2, i2 = b.step_onehot(onehot)
+        assert torch.equal(d1, d2) and torch.equal(r1, r2) and not i2.any().item()
+        assert torch.equal(a.state, b.state)
+
+
 def test_state_export_import_and_determinism(pkg):
     env = pkg.BatchedEnv(2048, seed=5)
     env.reset()
