@@ -781,46 +781,99 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       }
       const uint64_t hand = role == 0 ? h0 : role == 1 ? h1 : h2;
       const uint32_t info = (passes >= 2) ? mk_info(EMPTY, 0, 1) : trick;
-      const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
-      Pick pk{-1, 0, 0, 0, 0};
-      ACC(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
-      int n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
-      __builtin_amdgcn_wave_barrier();
-      if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
-        if (lane == 0) atomicOr(a.status, 2);
-        n = 0;
-      }
-      ACC(2);  // scan (planner + rounds + staging)
-      if (lane == 0) a.counts[t] = n;
-      s_rows += n;
       const int64_t base = t * a.stride;
-      for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
-        const uint64_t e = stage[j];
-        a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
-        if (IDS) a.ids[base + j] = sid[j];
+      const uint32_t draw = rl(draws, (int)(ply - dbase));
+      ACC(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
+      int n = 0, idx = -1;
+      uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, same value in every lane
+      uint64_t snib = 0;                  // ... as a nib, its category and value | len << 8
+      uint32_t scat = 0, svlv = 0;
+      const int lc0 = (int)(info & 0xFF);
+      if (lc0 != EMPTY && (lc0 <= QUADRIC || lc0 == BIGBANG)) {
+        // Two thirds of all plies follow a single, a pair, a triple, a bomb or the rocket.  Their
+        // legal list is pass + the higher groups of the same size + bombs + rocket
+        // (card.py:307-325): one lane per candidate, rows built arithmetically and stored
+        // straight into the slab; no record table, no staging.
+        //   lanes: 0 pass | 1..15 group of rank lane-1 | 16..28 bomb of rank lane-16 | 29 rocket
+        const int lv0 = (int)((info >> 8) & 0xFF);
+        const int cntr = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
+        const uint32_t mlc = (uint32_t)__ballot(cntr >= lc0) & (lc0 == SINGLE ? M15 : M13);
+        const uint32_t mq = (uint32_t)__ballot(cntr >= 4) & M13;
+        const bool rocket = lc0 != BIGBANG && ((uint32_t)__ballot(cntr >= 1) & JOKERS) == JOKERS;
+        const uint32_t ab = gt_mask(lv0);
+        const uint32_t cand = (lc0 == BIGBANG || lc0 == QUADRIC) ? 0u : (mlc & ab);
+        const uint32_t bombs = lc0 == BIGBANG ? 0u : lc0 == QUADRIC ? (mq & ab) : mq;
+        const int rr = (lane < 16 ? lane - 1 : lane - 16) & 15;
+        const bool ok = lane == 0 || (lane < 16 && ((cand >> rr) & 1u)) ||
+                        (lane >= 16 && lane < 29 && ((bombs >> rr) & 1u)) || (lane == 29 && rocket);
+        const uint64_t b = __ballot(ok);
+        n = __popcll(b);
+        const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        const uint32_t copies = lane == 0 ? 0u : lane < 16 ? (uint32_t)lc0 : 4u;  // category == group size here
+        const uint32_t dv = copies << (8 * (rr & 3));
+        const int w = rr >> 2;
+        uint4 row = make_uint4(w == 0 ? dv : 0u, w == 1 ? dv : 0u, w == 2 ? dv : 0u, (w == 3 ? dv : 0u) | (copies << 24));
+        if (lane == 29) row = make_uint4(0, 0, 0, 0x00010100u | ((uint32_t)BIGBANG << 24));
+        if (ok) {
+          a.rows[base + pre] = row;
+          if (IDS) a.ids[base + pre] = lane == 0 ? 0 : lane < 16 ? (lc0 == SINGLE ? 1 : lc0 == DOUBLE ? 16 : lc0 == TRIPLE ? 29 : 42) + rr
+                                      : lane < 29 ? 42 + rr : ID_BIGBANG;
+        }
+        if (lane == 0) a.counts[t] = n;
+        s_rows += n;
+        ACC(2);
+        idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
+        const int src = __builtin_ctzll(__ballot(ok && pre == idx));
+        c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
+        const int sr = (src < 16 ? src - 1 : src - 16) & 15;
+        if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
+        else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); }
+        else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); }
+        ACC(3);
+      } else {
+        const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
+        Pick pk{-1, 0, 0, 0, 0};
+        n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
+        __builtin_amdgcn_wave_barrier();
+        if (n > STAGE_CAP || n > a.stride) {  // cannot happen for a <= 20-card hand; never index past the slab
+          if (lane == 0) atomicOr(a.status, 2);
+          n = 0;
+        }
+        ACC(2);  // scan (planner + rounds + staging)
+        if (lane == 0) a.counts[t] = n;
+        s_rows += n;
+        for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
+          const uint64_t e = stage[j];
+          a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
+          if (IDS) a.ids[base + j] = sid[j];
+        }
+        ACC(3);  // flush rows
+        if (n > 0) {
+          idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83
+          const uint64_t e = stage[idx];           // LDS broadcast read
+          const uint64_t anib = e & 0x0FFFFFFFFFFFFFFFull;
+          const uint32_t acat = (uint32_t)(e >> 60);
+          c = unpack_row(anib, acat);
+          snib = (uint64_t)rfl((uint32_t)anib) | ((uint64_t)rfl((uint32_t)(anib >> 32)) << 32);
+          scat = rfl(acat);
+          svlv = rfl((uint32_t)svl[idx]);
+        }
       }
-      ACC(3);  // flush rows
       tr1.y |= (uint32_t)n & 0xFFFF;
       if (n <= 0) {
         tr1.x |= 2u << 24;
       } else {
-        const int idx = (int)__umulhi(rl(draws, (int)(ply - dbase)), (uint32_t)n);  // random.choice, envi.py:83
-        const uint64_t e = stage[idx];                       // LDS broadcast read
-        const uint64_t anib = e & 0x0FFFFFFFFFFFFFFFull;
-        const uint32_t acat = (uint32_t)(e >> 60);
-        const uint4 c = unpack_row(anib, acat);              // the chosen row, same value in every lane
-        const uint32_t cw3 = c.w & 0x00FFFFFFu;
-        const uint32_t ncards = (uint32_t)nib_sum(anib);
-        if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
-          R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
-        } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
-          R.x += c.x; R.y += c.y; R.z += c.z; R.w += cw3;
-        } else if (lane == DDZ_F_RECENT0 + role) {
-          R = c;
+        if (snib) {  // a pass (half of all plies) moves no card: only recent_handout and the turn change
+          const uint32_t cw3 = c.w & 0x00FFFFFFu;
+          const uint32_t ncards = (uint32_t)nib_sum(snib);
+          if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
+            R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
+          } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
+            R.x += c.x; R.y += c.y; R.z += c.z; R.w += cw3;
+          }
         }
+        if (lane == DDZ_F_RECENT0 + role) R = c;
         // carried scalars
-        const uint64_t snib = (uint64_t)rfl((uint32_t)anib) | ((uint64_t)rfl((uint32_t)(anib >> 32)) << 32);
-        const uint32_t scat = rfl(acat), svlv = rfl((uint32_t)svl[idx]);
         const uint64_t hnew = hand - snib;
         if (role == 0) h0 = hnew; else if (role == 1) h1 = hnew; else h2 = hnew;
         if (snib) { trick = scat | (svlv << 8); passes = 0; } else { passes += 1; }
