@@ -106,7 +106,8 @@ constexpr int EM_COUNT = 0;   // nothing (list size only)
 constexpr int EM_WRITE = 1;   // rows (+ids) into the CSR list at base + running index
 constexpr int EM_PICK = 2;    // EM_WRITE + capture the row with list index pk.want
 constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS staging list
-constexpr int STAGE_CAP = 512;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py)
+constexpr int STAGE_CAP = 500;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py);
+                                 // 500 keeps k_rollout's block at 53 KB of LDS = three blocks per CU
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
   int want;
@@ -199,11 +200,19 @@ __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
 // record fetched from memory costs ~1000 cycles; staged once per block it costs an LDS read.
 constexpr int HOT_IDS = ID_THREE_ONE_LINE;  // 526
 constexpr int HOT_SLOTS = HOT_IDS + 1;
-struct HotTab {
+template <bool WITH_ROWS>
+struct HotTabT {  // WITH_ROWS = false: kernels that stage packed rows only (k_rollout) save 8.4 KB of LDS
+  static constexpr bool HAS_ROWS = WITH_ROWS;
   uint4 meta[HOT_SLOTS + 1];
-  uint4 rows[HOT_SLOTS + 1];
+  uint4 rows[WITH_ROWS ? HOT_SLOTS + 1 : 1];
   uint32_t combo[COMBO_WORDS + 2];
 };
+using HotTab = HotTabT<true>;
+
+// componentwise select (a ?: on whole uint4s is lowered to a lane-indexed scratch array)
+__device__ __forceinline__ uint4 sel4(bool c, const uint4& a, const uint4& b) {
+  return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
 
 // the action a lane is looking at, however its record was obtained
 template <int EM, bool IDS>
@@ -242,8 +251,8 @@ __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int c
 // ids [id0, id0 + count) of the hot part of the action space (or the rocket): records in LDS.
 //   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
 //             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
-template <int EM, bool IDS>
-__device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, uint64_t hand8, const Follow& f,
+template <int EM, bool IDS, class HT>
+__device__ __forceinline__ int scan_ids(int id0, int count, const HT& hot, uint64_t hand8, const Follow& f,
                                         int lane, const Out& o, int n, Pick& pk) {
   constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
   constexpr uint64_t H8 = 0x8888888888888888ull;
@@ -253,7 +262,8 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, u
     const bool in = j < count;
     const int jj = in ? j : 0, id = id0 + jj;
     const uint4 m = hot.meta[slot0 + jj];
-    const uint4 row = ROWS ? hot.rows[slot0 + jj] : make_uint4(0, 0, 0, 0);
+    static_assert(!ROWS || HT::HAS_ROWS, "this emission mode reads the unpacked rows");
+    const uint4 row = ROWS ? hot.rows[HT::HAS_ROWS ? slot0 + jj : 0] : make_uint4(0, 0, 0, 0);
     const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
     const bool sub = ((hand8 - nib) & H8) == H8;
     const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
@@ -268,9 +278,9 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HotTab& hot, u
 // (ranks [s, s + gap) removed from the remains list), kicker set j = combination list entry j
 // with `mult` cards per kicker; ids idb + j.  The planner has already applied the follow
 // filter (category, len, value are those of the block), so legal <=> subset of the hand.
-template <int EM, bool IDS>
+template <int EM, bool IDS, class HT>
 __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_t mainnib, int s, int gap, int mult,
-                                           int cat, const HotTab& hot, uint64_t hand8, int lane, const Out& o,
+                                           int cat, const HT& hot, uint64_t hand8, int lane, const Out& o,
                                            int n, Pick& pk) {
   constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
   constexpr uint64_t H8 = 0x8888888888888888ull;
@@ -295,8 +305,8 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
 // (wave-uniform, scalar); ranges are visited in ascending id order.  Everything a range
 // admits too generously is rejected per id by scan_ids, so the planner only has to be a
 // superset -- and cheap.
-template <int EM, bool IDS>
-__device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int lane, const Out& o, Pick& pk) {
+template <int EM, bool IDS, class HT>
+__device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
   const Follow f = follow_of(info);
   const uint64_t hand8 = hand | 0x8888888888888888ull;
@@ -385,13 +395,13 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HotTab& hot, int la
 
 // every thread of the block copies its share of the hot records into LDS (callers issue
 // their own independent global loads first so that all of them are in flight together)
-template <int NT>
-__device__ __forceinline__ void hot_fill(HotTab& hot) {
+template <int NT, class HT>
+__device__ __forceinline__ void hot_fill(HT& hot) {
 #pragma unroll
   for (int i = threadIdx.x; i < HOT_SLOTS; i += NT) {
     const int id = i < HOT_IDS ? i : ID_BIGBANG;
     hot.meta[i] = g_tab[2 * id + 1];
-    hot.rows[i] = g_tab[2 * id];
+    if (HT::HAS_ROWS) hot.rows[i] = g_tab[2 * id];
   }
 #pragma unroll
   for (int i = threadIdx.x; i < COMBO_WORDS; i += NT) hot.combo[i] = g_combo[i];
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         if (a.reward) a.reward[t] = (int8_t)o_reward;
         if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
       }
-      if (a.traj && lane < 2) a.traj[2 * t + lane] = lane == 0 ? tr0 : tr1;
+      if (a.traj && lane < 2) a.traj[2 * t + lane] = sel4(lane == 0, tr0, tr1);
     }
     if (RESET) {
       const uint8_t* mask = (const uint8_t*)a.sel;
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #else
 #define ACC(k) do { } while (0)
 #endif
-  __shared__ HotTab hot;
+  __shared__ HotTabT<false> hot;
   __shared__ uint64_t s_stage[WPB][STAGE_CAP];
   __shared__ uint16_t s_svl[WPB][STAGE_CAP];
   __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       if (!active) {  // frozen table (never dealt / finished without auto-reset): empty list
         if (lane == 0) a.counts[t] = 0;
         tr1.x |= ((mx >> 8) & 0xFF) << 8 | 2u << 24;
-        if (tj && lane < 2) tj[lane] = lane == 0 ? tr0 : tr1;
+        if (tj && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
         if (tj) tj += 2 * a.T;
         continue;
       }
@@ -896,7 +906,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         }
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
       }
-      if (tj && lane < 2) tj[lane] = lane == 0 ? tr0 : tr1;
+      if (tj && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
       if (tj) tj += 2 * a.T;
       ACC(4);  // pick + apply + deal + state/trajectory stores
       __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
