@@ -23,20 +23,28 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (
 
 
 def cpu_baseline(tables, budget_s):
-    """Oracle (CPU port of the same rules/env) on the host cores of this box, 1 thread."""
+    """Oracle (CPU port of the same rules/env) on the host cores of this box: one thread, then the
+    tables split over all cores this process may use (tables are independent)."""
     from oracle import oracle
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
     env = oracle.OracleEnv(tables, seed=0)
     env.reset()
     t0 = time.perf_counter()
-    plies, _, _ = env.rollout_random(3)
+    env.rollout_random(3)
     per_iter = (time.perf_counter() - t0) / 3
-    n = max(3, min(2000, int(budget_s / max(per_iter, 1e-6))))
+    n1 = max(3, min(2000, int(0.4 * budget_s / max(per_iter, 1e-6))))
     t0 = time.perf_counter()
-    plies, legal, eps = env.rollout_random(n)
-    dt = time.perf_counter() - t0
-    return {"value": plies / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} lock-step iterations x {tables} tables (oracle/ddz_oracle.c, dense "
-                      f"13,527-row scan per state), {dt:.1f} s"}
+    plies1, _, _ = env.rollout_random(n1)
+    dt1 = time.perf_counter() - t0
+    nm = max(3, min(20000, int(0.6 * budget_s * cores / max(per_iter, 1e-6))))
+    t0 = time.perf_counter()
+    pliesm, _, _ = oracle.rollout_random_mt(env, nm, cores)
+    dtm = time.perf_counter() - t0
+    return {"value": pliesm / dtm, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "single_core_value": plies1 / dt1,
+            "sample": f"{nm} lock-step iterations x {tables} tables over {cores} threads in {dtm:.1f} s "
+                      f"(and {n1} iterations on 1 thread in {dt1:.1f} s); oracle/ddz_oracle.c, dense "
+                      "13,527-row scan per state"}
 
 
 def main():
@@ -130,11 +138,22 @@ def main():
     dominant = "k_rollout"
     ach = b_launch / dur_launch / 1e9
     traffic = None
+    issue = None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            per_step = json.load(open(tfile)).get(dominant, {}).get("hbm_bytes_per_env_step")
+            prof = json.load(open(tfile)).get(dominant, {})
+            per_step = prof.get("hbm_bytes_per_env_step")
             traffic = per_step * steps_timed if per_step is not None else None
+            # the bound this integer path really runs into: vector-ALU issue slots.  Instructions
+            # per env step and the clock come from the committed PMC pass, the rate is live
+            v = prof.get("valu")
+            if v:
+                peak = 256 * 4 * v["clock_GHz"] * 1e9 / 4  # wave-instructions/s, 4 cycles each per SIMD16
+                ach_i = v["SQ_INSTS_VALU_per_env_step"] * steps_timed / dur_launch
+                issue = {"bound": "valu-issue", "achieved": ach_i / 1e9, "peak": peak / 1e9,
+                         "unit": "G wave-instr/s", "frac": ach_i / peak,
+                         "valu_insts_per_env_step": v["SQ_INSTS_VALU_per_env_step"]}
         except Exception:
             traffic = None
 
@@ -165,7 +184,7 @@ def main():
                          "launch_us": dur_launch * 1e6, "env_steps_per_launch": steps_timed,
                          "us_per_iteration": dur_launch * 1e6 / n_timed,
                          "algorithmic_bytes_per_env_step": b_step,
-                         "algorithmic_bytes_per_launch": b_launch},
+                         "algorithmic_bytes_per_launch": b_launch, "issue": issue},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)

@@ -6,7 +6,7 @@ never imported from here.)"""
 import ctypes as C
 import os
 
-from .build import LIB
+from .build import LIB as _DEFAULT_LIB
 
 _lib = None
 
@@ -51,6 +51,7 @@ def lib():
     """Load libddz_hip.so; raises (never falls back) when it is absent."""
     global _lib
     if _lib is None:
+        LIB = os.environ.get("DDZ_HIP_LIB") or _DEFAULT_LIB  # override: kernel experiments (tools/variants.py)
         if not os.path.exists(LIB):
             raise DdzError(
                 f"{LIB} is missing: build it with `python __graft_entry__.py build` "

@@ -164,6 +164,30 @@ class OracleEnv:
         return plies, sl.value, ep.value
 
 
+def rollout_random_mt(env, n_iters, threads):
+    """The same rollout with the tables split over `threads` host threads (tables are independent,
+    game.py:28; RNG is keyed by the global table id, so the result equals the 1-thread run).
+    ctypes releases the GIL around the C call."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib().ddzo_init()
+    T = env.T
+    threads = max(1, min(int(threads), T))
+    cuts = [T * i // threads for i in range(threads + 1)]
+    st = env.state.reshape(T, -1)
+
+    def run(i):
+        lo, hi = cuts[i], cuts[i + 1]
+        sl, ep = C.c_int64(0), C.c_int64(0)
+        part = st[lo:hi]
+        plies = lib().ddzo_rollout_random(_ptr(part), hi - lo, env.seed, env.gid_base + lo, int(n_iters),
+                                          C.byref(sl), C.byref(ep))
+        return plies, sl.value, ep.value
+
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(run, range(threads)))
+    return tuple(sum(r[k] for r in res) for k in range(3))
+
+
 def rows_to_onehot(rows):
     r = np.ascontiguousarray(rows, np.int8).reshape(-1, ROW)
     out = np.zeros((r.shape[0], 15, 4), np.float32)

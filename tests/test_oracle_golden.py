@@ -156,3 +156,16 @@ def test_step_rows_and_illegal(oracle):
     env.legal()
     done, reward, illegal, _ = env.step(oracle.STEP_CHOICE, np.full(8, 10 ** 6, np.int32), auto_reset=False)
     assert illegal.all()
+
+
+def test_rollout_threads_equal_single_thread():
+    """bench.py's all-core CPU baseline: splitting the tables over threads changes nothing
+    (RNG keyed by the global table id)."""
+    from oracle import oracle
+    a = oracle.OracleEnv(96, seed=5)
+    b = oracle.OracleEnv(96, seed=5)
+    a.reset(); b.reset()
+    ra = a.rollout_random(40)
+    rb = oracle.rollout_random_mt(b, 40, 5)
+    assert ra == rb
+    assert np.array_equal(a.state, b.state)

@@ -17,8 +17,9 @@ for T in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "102
     for _ in range(3):
         best = min(best, env.rollout_random_timed(iters))
     st = env.stats()
+    chk = int(env.state_export().to(torch.int64).sum().item()) if hasattr(env, "state_export") else 0
     print(f"T={T:7d} tpw={os.environ.get('DDZ_TPW', 'auto'):>4s}  {best / iters * 1e3:8.3f} us/iter  "
-          f"{T * iters / best / 1e3:10.1f} M steps/s  meanA={st['legal_rows'] / st['plies']:.2f} status={env.status()}",
+          f"{T * iters / best / 1e3:10.1f} M steps/s  meanA={st['legal_rows'] / st['plies']:.2f} status={env.status()} chk={chk} eps={st['episodes']}",
           flush=True)
     del env
     torch.cuda.empty_cache()
