@@ -251,7 +251,7 @@ __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int c
 // ids [id0, id0 + count) of the hot part of the action space (or the rocket): records in LDS.
 //   legal <=> counter_subset(action, hand) (utils.py:16-22, SWAR per nibble) and
 //             (lead or pass or bigger_than(action, last)) (utils.py:53-60, card.py:307-325)
-template <int EM, bool IDS, class HT>
+template <int EM, bool IDS, bool LEAD, class HT>
 __device__ __forceinline__ int scan_ids(int id0, int count, const HT& hot, uint64_t hand8, const Follow& f,
                                         int lane, const Out& o, int n, Pick& pk) {
   constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
@@ -267,7 +267,7 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HT& hot, uint6
     const uint64_t nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
     const bool sub = ((hand8 - nib) & H8) == H8;
     const int val = m.z & 0xFF, len = (m.z >> 8) & 0xFF, cat = (m.z >> 16) & 0xFF;
-    const bool gate = f.lead || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
+    const bool gate = LEAD || id == 0 || cat == BIGBANG || (cat == QUADRIC && (f.lc != QUADRIC || val > f.lv)) ||
                       (cat == f.lc && f.lc != QUADRIC && len == f.ll && val > f.lv);
     n = scan_emit<EM, IDS>(in && sub && gate, id, nib, cat, (int)(m.z & 0xFFFF), row, o, n, pk);
   }
@@ -305,10 +305,8 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
 // (wave-uniform, scalar); ranges are visited in ascending id order.  Everything a range
 // admits too generously is rejected per id by scan_ids, so the planner only has to be a
 // superset -- and cheap.
-template <int EM, bool IDS, class HT>
-__device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
-  if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
-  const Follow f = follow_of(info);
+template <int EM, bool IDS, bool LEAD, class HT>
+__device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const HT& hot, int lane, const Out& o, Pick& pk) {
   const uint64_t hand8 = hand | 0x8888888888888888ull;
   const int cnt = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
   const uint32_t m1 = (uint32_t)__ballot(cnt >= 1) & M15;
@@ -316,22 +314,22 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, 
   const uint32_t m3 = (uint32_t)__ballot(cnt >= 3) & M13;
   const uint32_t m4 = (uint32_t)__ballot(cnt >= 4) & M13;
   int n = 0;
-  auto scan = [&](int id0, int count) { n = scan_ids<EM, IDS>(id0, count, hot, hand8, f, lane, o, n, pk); };
-  if (!f.lead && f.lc == BIGBANG) {  // nothing beats the rocket: pass only (card.py:312-313)
+  auto scan = [&](int id0, int count) { n = scan_ids<EM, IDS, LEAD>(id0, count, hot, hand8, f, lane, o, n, pk); };
+  if (!LEAD && f.lc == BIGBANG) {  // nothing beats the rocket: pass only (card.py:312-313)
     scan(0, 1);
     return n;
   }
-  if (f.lead) scan(1, 54); else scan(0, 55);  // [pass,] singles, pairs, triples, bombs
-  const uint32_t above = f.lead ? M15 : gt_mask(f.lv);
-  if (f.lead || f.lc == THREE_ONE || f.lc == THREE_TWO) {  // mains m..M of card.py:69-82
+  if (LEAD) scan(1, 54); else scan(0, 55);  // [pass,] singles, pairs, triples, bombs
+  const uint32_t above = LEAD ? M15 : gt_mask(f.lv);
+  if (LEAD || f.lc == THREE_ONE || f.lc == THREE_TWO) {  // mains m..M of card.py:69-82
     const uint32_t mains = m3 & above;
     if (mains) {
       const int lo = __builtin_ctz(mains), hi = 31 - __builtin_clz(mains);
-      if (f.lead || f.lc == THREE_ONE) scan(ID_THREE_ONE + 14 * lo, 14 * (hi - lo + 1));
-      if (f.lead || f.lc == THREE_TWO) scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
+      if (LEAD || f.lc == THREE_ONE) scan(ID_THREE_ONE + 14 * lo, 14 * (hi - lo + 1));
+      if (LEAD || f.lc == THREE_TWO) scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
     }
   }
-  if (f.lead) {  // chains (card.py:86-105): the three categories are contiguous ids
+  if (LEAD) {  // chains (card.py:86-105): the three categories are contiguous ids
     const bool a = run_starts(m1 & M12, 5) != 0, b = run_starts(m2 & M12, 3) != 0, c = run_starts(m3 & M12, 2) != 0;
     if (a || b || c) {
       const int lo = a ? ID_SINGLE_LINE : b ? ID_DOUBLE_LINE : ID_TRIPLE_LINE;
@@ -352,7 +350,7 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, 
   //   3+2: sizes C(13-L, L) = 55, 120, 126        (L = 2..4)
   auto planes = [&](int cat, int hi, int idb0, int mult, int list2, int list3, int list4, int list5) {
     const uint32_t mm = m3 & M12;
-    if (!(f.lead || f.lc == cat)) return;
+    if (!(LEAD || f.lc == cat)) return;
     for (uint32_t st = mm & (mm >> 1); st; st &= st - 1) {
       const int s = __builtin_ctz(st);
       const int runlen = __builtin_ctz(~(mm >> s));  // consecutive triples from s
@@ -366,7 +364,7 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, 
       }
       const int maxL = runlen < hi ? runlen : hi;
       for (int L = 2; L <= maxL && s + L <= 12; ++L) {
-        if (!(f.lead || (L == f.ll && s > f.lv))) continue;
+        if (!(LEAD || (L == f.ll && s > f.lv))) continue;
         const int idb = idb0 + before + (L > 2 ? sz2 : 0) + (L > 3 ? sz3 : 0) + (L > 4 ? sz4 : 0);
         const int size = L == 2 ? sz2 : L == 3 ? sz3 : L == 4 ? sz4 : 252;
         const int list = L == 2 ? list2 : L == 3 ? list3 : L == 4 ? list4 : list5;
@@ -378,19 +376,28 @@ __device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, 
   planes(THREE_ONE_LINE, 5, ID_THREE_ONE_LINE, 1, 1, 4, 6, 8);
   planes(THREE_TWO_LINE, 4, ID_THREE_TWO_LINE, 2, 3, 5, 7, 7);
   if ((m1 & JOKERS) == JOKERS) scan(ID_BIGBANG, 1);  // rocket (card.py:134, :314-315)
-  if (f.lead || f.lc == FOUR_TAKE_ONE)                // card.py:139-143 (no joker pair: :142)
+  if (LEAD || f.lc == FOUR_TAKE_ONE)                // card.py:139-143 (no joker pair: :142)
     for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
       const int q = __builtin_ctz(qm);
       n = scan_combos<EM, IDS>(0, 90, ID_FOUR_TAKE_ONE + 90 * q, 4ull << (4 * q), q, 1, 1, FOUR_TAKE_ONE, hot, hand8,
                                lane, o, n, pk);
     }
-  if (f.lead || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
+  if (LEAD || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
     for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
       const int q = __builtin_ctz(qm);
       n = scan_combos<EM, IDS>(2, 66, ID_FOUR_TAKE_TWO + 66 * q, 4ull << (4 * q), q, 1, 2, FOUR_TAKE_TWO, hot, hand8,
                                lane, o, n, pk);
     }
   return n;
+}
+
+
+// lead and follow are separate instantiations: on lead every gate is true at compile time
+template <int EM, bool IDS, class HT>
+__device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
+  if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
+  const Follow f = follow_of(info);
+  return f.lead ? plan_scan_t<EM, IDS, true>(hand, f, hot, lane, o, pk) : plan_scan_t<EM, IDS, false>(hand, f, hot, lane, o, pk);
 }
 
 // every thread of the block copies its share of the hot records into LDS (callers issue
@@ -746,6 +753,16 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   uint16_t* sid = s_sid[IDS ? wv : 0];
   int s_ply = 0;
   int64_t s_rows = 0;
+  // per-lane constants of the fast path (VGPRs; opaque so that they are not rebuilt from spilled lane masks)
+  const int f_rr = (lane < 16 ? lane - 1 : lane - 16) & 15;
+  uint32_t f_bit = lane < 32 ? 1u << lane : 0u;                     // this lane's bit in a 32-bit candidate mask
+  uint32_t f_sh = 8u * (uint32_t)(f_rr & 3);                         // byte position of the rank in its row word
+  uint32_t f_w0 = (f_rr >> 2) == 0 ? ~0u : 0u, f_w1 = (f_rr >> 2) == 1 ? ~0u : 0u;
+  uint32_t f_w2 = (f_rr >> 2) == 2 ? ~0u : 0u, f_w3 = (f_rr >> 2) == 3 ? ~0u : 0u;
+  uint32_t f_grp = (lane >= 1 && lane < 16) ? ~0u : 0u;             // lanes 1..15: a group of the led size
+  uint32_t f_c4 = (lane >= 16 && lane < 29) ? 4u : 0u;              // lanes 16..28: a bomb
+  uint32_t f_rk = lane == 29 ? (0x00010100u | ((uint32_t)BIGBANG << 24)) : 0u;  // lane 29: the rocket row
+  asm volatile("" : "+v"(f_bit), "+v"(f_sh), "+v"(f_w0), "+v"(f_w1), "+v"(f_w2), "+v"(f_w3), "+v"(f_grp), "+v"(f_c4), "+v"(f_rk));
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     ACC(0);  // prologue (or previous table's tail)
@@ -817,17 +834,15 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         const uint32_t ab = gt_mask(lv0);
         const uint32_t cand = (lc0 == BIGBANG || lc0 == QUADRIC) ? 0u : (mlc & ab);
         const uint32_t bombs = lc0 == BIGBANG ? 0u : lc0 == QUADRIC ? (mq & ab) : mq;
-        const int rr = (lane < 16 ? lane - 1 : lane - 16) & 15;
-        const bool ok = lane == 0 || (lane < 16 && ((cand >> rr) & 1u)) ||
-                        (lane >= 16 && lane < 29 && ((bombs >> rr) & 1u)) || (lane == 29 && rocket);
-        const uint64_t b = __ballot(ok);
-        n = __popcll(b);
-        const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        const uint32_t copies = lane == 0 ? 0u : lane < 16 ? (uint32_t)lc0 : 4u;  // category == group size here
-        const uint32_t dv = copies << (8 * (rr & 3));
-        const int w = rr >> 2;
-        uint4 row = make_uint4(w == 0 ? dv : 0u, w == 1 ? dv : 0u, w == 2 ? dv : 0u, (w == 3 ? dv : 0u) | (copies << 24));
-        if (lane == 29) row = make_uint4(0, 0, 0, 0x00010100u | ((uint32_t)BIGBANG << 24));
+        const int rr = f_rr;
+        // the candidate mask is scalar: bit 0 pass | 1..15 groups | 16..28 bombs | 29 rocket
+        const uint32_t okm = 1u | (cand << 1) | (bombs << 16) | (rocket ? 1u << 29 : 0u);
+        const bool ok = (okm & f_bit) != 0;
+        n = __builtin_popcount(okm);
+        const int pre = (int)__builtin_amdgcn_mbcnt_lo(okm, 0u);
+        const uint32_t copies = ((uint32_t)lc0 & f_grp) | f_c4;  // category == group size here
+        const uint32_t dv = copies << f_sh;
+        const uint4 row = make_uint4(dv & f_w0, dv & f_w1, dv & f_w2, (dv & f_w3) | (copies << 24) | f_rk);
         if (ok) {
           a.rows[base + pre] = row;
           if (IDS) a.ids[base + pre] = lane == 0 ? 0 : lane < 16 ? (lc0 == SINGLE ? 1 : lc0 == DOUBLE ? 16 : lc0 == TRIPLE ? 29 : 42) + rr
@@ -837,7 +852,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         s_rows += n;
         ACC(2);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
-        const int src = __builtin_ctzll(__ballot(ok && pre == idx));
+        const int src = __builtin_ctz((uint32_t)__ballot(pre == idx) & okm);
         c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
         const int sr = (src < 16 ? src - 1 : src - 16) & 15;
         if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
