@@ -850,7 +850,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         }
         if (lane == 0) a.counts[t] = n;
         s_rows += n;
-        ACC(2);
+        ACC(5);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
         const int src = __builtin_ctz((uint32_t)__ballot(pre == idx) & okm);
         c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
         else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); }
         else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); }
-        ACC(3);
+        ACC(5);  // fast path: list + pick
       } else {
         const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
         Pick pk{-1, 0, 0, 0, 0};
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   }
 #ifdef DDZ_STAMP
   if (g_stamps && lane == 0 && ntab > 0)
-    for (int q = 0; q < 5; ++q) g_stamps[8 * t0 + q] = acc[q];
+    for (int q = 0; q < 6; ++q) g_stamps[8 * t0 + q] = acc[q];
 #endif
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
     int64_t* ws = a.wave_stats + 4 * wave;

@@ -9,8 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "doudizhu-rl_amd", "csrc")
-lib = os.path.join(csrc, "libddz_hip.so")
-if os.environ.get("STAMP_BUILD", "1") == "1":
+lib = os.environ.get("DDZ_HIP_LIB") or os.path.join(csrc, "libddz_hip.so")
+if os.environ.get("STAMP_BUILD", "1") == "1" and not os.environ.get("DDZ_HIP_LIB"):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                            "-DDDZ_STAMP=1", "-o", lib, os.path.join(csrc, "ddz_engine.hip")])
 import torch  # noqa: E402
@@ -30,8 +30,8 @@ env.rollout_random(N_IT)
 torch.cuda.synchronize()
 import numpy as np
 s = buf.cpu().numpy().astype(np.float64)
-names = ["prologue", "iter setup", "scan", "flush", "pick+apply+stores"]
-tot = s[:, :5].sum(1)
+names = ["prologue", "iter setup", "scan (generic)", "flush+pick (generic)", "apply+stores", "fast path list+pick"]
+tot = s[:, :6].sum(1)
 print(f"T={T}, {N_IT} in-launch iterations; cycles per wave per iteration (s_memtime):")
 print(f"  total/iter  mean {tot.mean()/N_IT:8.0f}  max {tot.max()/N_IT:8.0f}")
 for k, nm in enumerate(names):
