@@ -3,11 +3,12 @@
 
   python bench.py --gpus N --steps K --warmup W
 A "step" is one lock-step iteration of the hot path over all tables of this rank:
-legal-move enumeration into the CSR list + random-policy action application with
+legal-move enumeration into the per-table list + random-policy action application with
 auto-reset (configs[1]: 4096 tables per MI355X, random policy, legal-move list only).
-Weak scaling: every GPU runs 4096 tables of the global id range; for N > 1 the packed
-trajectories of the K steps are all-gathered over RCCL inside the timed region (the only
-exchange the path has).  Rank 0 prints ONE JSON line.
+Weak scaling: every GPU runs 4096 tables of the global id range and the timed region is the
+same at every N (tables are independent: no data-path collective).  For N > 1 the path's one
+exchange -- packed trajectories gathered to rank 0 over RCCL -- is measured right after the
+headline region and reported in config.exchange.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -55,6 +56,9 @@ def main():
     ap.add_argument("--tables", type=int, default=4096, help="tables per GPU (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--exchange-steps", type=int, default=500, help="N > 1: iterations of the trajectory-gather leg")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on ONE GPU (all ranks on cuda:0, gloo, host-staged gather): control-flow rehearsal only")
     a = ap.parse_args()
 
     import torch
@@ -67,10 +71,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if a.rehearse else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     T = a.tables
     total_tables = T * world
@@ -78,41 +85,21 @@ def main():
     env = pkg.BatchedEnv(T, seed=0, device=dev, table_id_base=base, want_ids=False)
     env.reset()
     K, W = a.steps, a.warmup
-    # N > 1: the batch's packed trajectories go to the learner (rank 0) over RCCL in two
-    # half-batches; the gather of the first half overlaps the rollout of the second one, the
-    # gather of the second half overlaps the next batch (steady state) and runs after the clock
-    half = max(1, K // 2)
-    shard = [T] * world
-    traj_a = torch.zeros((half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
-    traj_b = torch.zeros((max(1, K - half), T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The timed region is the same at every N: K lock-step iterations of this rank's 4096 tables.  Tables
+    # are independent, so there is no data-path collective while stepping (weak scaling).
     env.rollout_random(W)
-    if world > 1:  # warm the collective too
-        ddist.gather_trajectories(traj_a[:1].contiguous(), dst=0, shard_sizes=shard)
     s0 = env.stats()  # cumulative counters so far (sync)
     barrier()
     t0 = time.perf_counter()
-    if world == 1:
-        env.rollout_random(K)
-    else:
-        env.rollout_random(half, traj=traj_a)
-        pending = ddist.gather_trajectories(traj_a, dst=0, async_op=True, shard_sizes=shard)
-        if K - half > 0:
-            env.rollout_random(K - half, traj=traj_b)
-        gathered = pending.result()
+    env.rollout_random(K)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        if K - half > 0:
-            tail = ddist.gather_trajectories(traj_b, dst=0, shard_sizes=shard)
-        if rank == 0:
-            assert gathered.shape == (half, total_tables, pkg.TRAJ_BYTES)
-        del traj_a, traj_b
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -121,6 +108,45 @@ def main():
     st = {k: s1[k] - s0[k] for k in s1}
     status = env.status()
     assert st["plies"] == T * K and status == 0, (st, status)
+
+    # The path's one exchange, measured beside the headline, never inside it: every ply also
+    # writes its 32-byte trajectory record and the batch goes to the learner (rank 0) over RCCL in two
+    # half-batches; the gather of the first half overlaps the rollout of the second one.
+    exchange = None
+    if world > 1:
+        KX = max(2, min(K, a.exchange_steps))
+        half = KX // 2
+        shard = [T] * world
+        stage = (lambda x: x.cpu()) if a.rehearse else (lambda x: x)
+        traj_a = torch.zeros((half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
+        traj_b = torch.zeros((KX - half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
+        ddist.gather_trajectories(stage(traj_a[:1].contiguous()), dst=0, shard_sizes=shard)  # warm the collective
+        barrier()
+        tx = time.perf_counter()
+        env.rollout_random(half, traj=traj_a)
+        if a.rehearse:
+            torch.cuda.synchronize(dev)
+        pending = ddist.gather_trajectories(stage(traj_a), dst=0, async_op=True, shard_sizes=shard)
+        env.rollout_random(KX - half, traj=traj_b)
+        if a.rehearse:
+            torch.cuda.synchronize(dev)
+        tail = ddist.gather_trajectories(stage(traj_b), dst=0, async_op=True, shard_sizes=shard)
+        ga, gb = pending.result(), tail.result()
+        barrier()
+        dtx = time.perf_counter() - tx
+        tmx = torch.tensor([dtx], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        dtx = float(tmx.item())
+        if rank == 0:
+            assert ga.shape == (half, total_tables, pkg.TRAJ_BYTES) and gb.shape == (KX - half, total_tables, pkg.TRAJ_BYTES)
+            rec = ddist.unpack_trajectory(gb[-1].to(dev))
+            assert int(rec["ply"].max()) < 400 and int(rec["role"].max()) <= 2
+        exchange = {"steps": KX, "env_steps_per_s_with_gather": total_tables * KX / dtx,
+                    "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_BYTES, "seconds": dtx,
+                    "note": "trajectory records (32 B per ply per table) written and gathered to rank 0, pipelined "
+                            "in two half-batches; measured after the headline region"}
+        del traj_a, traj_b, ga, gb
+        s1 = env.stats()
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
     # duration of the dominant kernel: all iterations run inside ONE k_rollout launch; two HIP
@@ -178,7 +204,7 @@ def main():
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
                        "list_layout": "slab (fixed-stride segment per table); packed-CSR variant of the "
                                       "same loop: %.4g env steps/s per GPU" % csr_rate,
-                       "trajectory_gather": world > 1},
+                       "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
                          "launch_us": dur_launch * 1e6, "env_steps_per_launch": steps_timed,
