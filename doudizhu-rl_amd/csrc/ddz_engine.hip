@@ -452,7 +452,7 @@ __device__ __forceinline__ uint32_t last_info(uint64_t n1, int c1, uint64_t n2, 
 // DDZ_STAMP: diagnostic build only (tools/stamp_probe.py): k_rollout accumulates s_memtime
 // deltas per phase into a debug buffer nothing else reads.
 #ifdef DDZ_STAMP
-__device__ unsigned long long* g_stamps = nullptr;  // [T][8]
+__device__ unsigned long long* g_stamps = nullptr;  // [T][16]
 #endif
 
 struct TableArgs {
@@ -725,7 +725,7 @@ template <bool IDS>
 __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #ifdef DDZ_STAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t_last = t_entry;
+  unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_entry;
 #define ACC(k)                                                       \
   do {                                                               \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
@@ -887,6 +887,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           scat = rfl(acat);
           svlv = rfl((uint32_t)svl[idx]);
         }
+        ACC(10);  // generic pick
       }
       tr1.y |= (uint32_t)n & 0xFFFF;
       if (n <= 0) {
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           }
         }
         if (lane == DDZ_F_RECENT0 + role) R = c;
+        ACC(6);  // row updates
         // carried scalars
         const uint64_t hnew = hand - snib;
         if (role == 0) h0 = hnew; else if (role == 1) h1 = hnew; else h2 = hnew;
@@ -913,6 +915,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         tr1.x |= (uint32_t)won << 8 | o_reward << 16;
         tr1.w = (uint32_t)idx;
         ply += 1;
+        ACC(7);  // carried scalars
         if (won) {  // auto-reset: next episode of this table
           if (lane == 0) {  // the wave owns its statistics slot: plain read-modify-write
             int64_t* ws = a.wave_stats + 4 * wave;
@@ -930,7 +933,9 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           role = role == 2 ? 0 : role + 1;  // lord -> down -> up, game.py:173-181
           if (lane == DDZ_F_META) R = make_uint4((uint32_t)role | (0xFFu << 16), my_hi | (ply & 0xFFFF), episode, mw);
         }
+        ACC(8);  // deal / turn change
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
+        ACC(9);  // state store
       }
       if (tj && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
       if (tj) tj += 2 * a.T;
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   }
 #ifdef DDZ_STAMP
   if (g_stamps && lane == 0 && ntab > 0)
-    for (int q = 0; q < 6; ++q) g_stamps[8 * t0 + q] = acc[q];
+    for (int q = 0; q < 12; ++q) g_stamps[16 * t0 + q] = acc[q];
 #endif
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
     int64_t* ws = a.wave_stats + 4 * wave;

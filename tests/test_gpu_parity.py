@@ -466,3 +466,69 @@ def test_env_view_matches_reference_api(pkg, oracle):
         r, done, _ = env.step_random()
         plies += 1
     assert r in (-1, 1) and 0 in env.left.tolist() and plies < 170
+
+
+def _plane_rich_hands(rng, n, cards):
+    """Random `cards`-card hands biased towards runs of triples / bombs (SURVEY 8d stress set:
+    the compaction worst case, lists of several hundred moves)."""
+    hands = np.zeros((n, 15), np.int8)
+    for i in range(n):
+        h = np.zeros(15, np.int64)
+        start = rng.integers(0, 8)
+        run = rng.integers(2, 6)
+        h[start:start + run] = rng.choice([3, 3, 3, 4], size=run)
+        left = cards - int(h.sum())
+        while left > 0:
+            r = rng.integers(0, 15)
+            cap = 1 if r >= 13 else 4
+            if h[r] < cap:
+                h[r] += 1
+                left -= 1
+        while h.sum() > cards:
+            r = rng.integers(0, 15)
+            if h[r] > 0:
+                h[r] -= 1
+        hands[i] = h
+    return hands
+
+
+@pytest.mark.parametrize("cards", [20, 17, 12])
+def test_get_moves_plane_rich_stress(pkg, oracle, golden, cards):
+    """Lead and follow lists of plane-rich hands (long lists, many kicker blocks) vs the oracle,
+    ids and rows, bit-exact; every category of `last` that such hands can answer."""
+    rng = np.random.default_rng(100 + cards)
+    table = golden("action_table.npz")
+    n = 600
+    hands = _plane_rich_hands(rng, n, cards)
+    lasts = np.zeros((n, 15), np.int8)
+    # a third lead, the rest follow a random action of a random category (small values: beatable)
+    cat = table["cat_range"]
+    for i in range(n):
+        if i % 3 == 0:
+            continue
+        c = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14])
+        pool = np.nonzero(cat == c)[0]
+        lasts[i] = table["rows"][pool[rng.integers(0, max(1, len(pool) // 3))]]
+    offsets, rows, ids = pkg.get_moves(torch.from_numpy(hands).to(_dev()), torch.from_numpy(lasts).to(_dev()))
+    offsets, rows, ids = offsets.cpu().numpy(), rows.cpu().numpy(), ids.cpu().numpy()
+    longest = 0
+    for i in range(n):
+        want = oracle.legal(hands[i], lasts[i] if lasts[i].any() else None)
+        got = ids[offsets[i]:offsets[i + 1]]
+        assert np.array_equal(got, want), (i, hands[i], lasts[i])
+        assert np.array_equal(rows[offsets[i]:offsets[i + 1], :15], table["rows"][want])
+        longest = max(longest, len(want))
+    assert longest > (150 if cards >= 17 else 40)  # the stress set does produce long lists
+
+
+def test_dqn_training_example_runs(pkg):
+    """N2 end to end: legal -> observe -> ragged Q -> select -> transitions -> TD step, 256 tables."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg3train", os.path.join(repo, "examples", "config3_dqn_train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--tables", "256", "--iters", "60"])
+    assert out["status"] == 0 and out["replay"] > 256 and out["episodes"] > 0
+    assert out["last_loss"] is not None and np.isfinite(out["last_loss"])

@@ -21,7 +21,7 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = pkg.BatchedEnv(T, seed=0, want_ids=False)
 env.reset()
 env.rollout_random(100)
-buf = torch.zeros((T, 8), dtype=torch.int64, device="cuda")
+buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
 raw = C.CDLL(lib)
 raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
 assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
@@ -30,8 +30,8 @@ env.rollout_random(N_IT)
 torch.cuda.synchronize()
 import numpy as np
 s = buf.cpu().numpy().astype(np.float64)
-names = ["prologue", "iter setup", "scan (generic)", "flush+pick (generic)", "apply+stores", "fast path list+pick"]
-tot = s[:, :6].sum(1)
+names = ["prologue", "iter setup", "scan (generic)", "flush (generic)", "trajectory + loop tail", "fast path list+pick", "row updates", "carried scalars", "deal / turn change", "state store", "pick (generic)", "-"]
+tot = s[:, :12].sum(1)
 print(f"T={T}, {N_IT} in-launch iterations; cycles per wave per iteration (s_memtime):")
 print(f"  total/iter  mean {tot.mean()/N_IT:8.0f}  max {tot.max()/N_IT:8.0f}")
 for k, nm in enumerate(names):
