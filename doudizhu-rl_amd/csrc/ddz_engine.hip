@@ -721,7 +721,7 @@ struct RolloutArgs {
   int64_t* legal_rows;
 };
 
-template <bool IDS>
+template <bool IDS, bool TRAJ>
 __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 #ifdef DDZ_STAMP
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -778,7 +778,10 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     if (role > 2) role = 0;
     const bool active = ((my >> 16) & 0xFF) && !((mx >> 8) & 0xFF);  // dealt and not done
     uint32_t ply = my & 0xFFFF, episode = mz;
-    uint64_t h0 = rl64(P, DDZ_F_HAND0), h1 = rl64(P, DDZ_F_HAND0 + 1), h2 = rl64(P, DDZ_F_HAND0 + 2);
+    // hands in turn order: hc = the actor's, hn = the next player's, hp = the previous player's; a ply
+    // rotates the three names (register moves) instead of selecting by role twice
+    uint64_t hc = rl64(P, DDZ_F_HAND0 + role), hn = rl64(P, DDZ_F_HAND0 + (role == 2 ? 0 : role + 1)),
+             hp = rl64(P, DDZ_F_HAND0 + (role == 0 ? 2 : role - 1));
     // the combo to beat (envi.py:103-109) as (trick, passes since it was played)
     uint32_t trick = mk_info(EMPTY, 0, 1);
     int passes = 0;
@@ -789,31 +792,35 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       else if (n2) { trick = info_of_row(n2, (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24)); passes = 1; }
     }
     // engine RNG draws for 64 consecutive plies at once: lane j holds the draw of ply dbase + j
-    uint32_t draws = 0, dbase = 0, depi = 0;
-    bool dvalid = false;
-    uint4* tj = a.traj ? a.traj + 2 * t : nullptr;  // record of (iteration, table)
+    uint32_t draws = 0, dnext = 64;  // lane dnext holds the next draw; 64 = refill
+    uint4* tj = TRAJ ? a.traj + 2 * t : nullptr;  // record of (iteration, table)
+    if (!active) {  // frozen table (never dealt / finished without auto-reset): empty lists, flagged records
+      if (lane == 0) a.counts[t] = 0;
+      if (TRAJ) {
+        const uint4 f0 = make_uint4(0, 0, 0, 0);
+        const uint4 f1 = make_uint4((uint32_t)role | ((mx >> 8) & 0xFF) << 8 | 2u << 24, ply << 16, episode, 0xFFFFFFFFu);
+        for (int it = (int)a.n_iters; it > 0; --it) {
+          if (lane < 2) tj[lane] = sel4(lane == 0, f0, f1);
+          tj += 2 * a.T;
+        }
+      }
+      continue;
+    }
     for (int it = (int)a.n_iters; it > 0; --it) {
       uint4 tr0 = make_uint4(0, 0, 0, 0);
       uint4 tr1 = make_uint4((uint32_t)role, ply << 16, episode, 0xFFFFFFFFu);
-      if (!active) {  // frozen table (never dealt / finished without auto-reset): empty list
-        if (lane == 0) a.counts[t] = 0;
-        tr1.x |= ((mx >> 8) & 0xFF) << 8 | 2u << 24;
-        if (tj && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
-        if (tj) tj += 2 * a.T;
-        continue;
-      }
-      if (!dvalid || depi != episode || ply - dbase >= 64u) {
-        dbase = ply; depi = episode; dvalid = true;
+      if (dnext >= 64u) {
+        dnext = 0;
         uint32_t qk0 = a.k0, qk1 = a.k1;  // opaque: round keys are computed here, not hoisted and spilled
         asm volatile("" : "+s"(qk0), "+s"(qk1));
         draws = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | (ply + (uint32_t)lane)), qk0, qk1).x;
       }
-      const uint64_t hand = role == 0 ? h0 : role == 1 ? h1 : h2;
+      const uint64_t hand = hc;
       // rfl: the combo to beat stays wave-uniform for the compiler, so the category dispatch below is
       // scalar branches (the carried state itself lives in VGPRs: measured faster than on the scalar unit)
       const uint32_t info = rfl((passes >= 2) ? mk_info(EMPTY, 0, 1) : trick);
       const int64_t base = t * a.stride;
-      const uint32_t draw = rl(draws, (int)(ply - dbase));
+      const uint32_t draw = rl(draws, (int)dnext);
       ACC(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
       int n = 0, idx = -1;
       uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, same value in every lane
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           if (IDS) a.ids[base + pre] = lane == 0 ? 0 : lane < 16 ? (lc0 == SINGLE ? 1 : lc0 == DOUBLE ? 16 : lc0 == TRIPLE ? 29 : 42) + rr
                                       : lane < 29 ? 42 + rr : ID_BIGBANG;
         }
-        if (lane == 0) a.counts[t] = n;
+        a.counts[t] = n;  // every lane stores the same word: no exec-mask change
         s_rows += n;
         ACC(5);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           n = 0;
         }
         ACC(2);  // scan (planner + rounds + staging)
-        if (lane == 0) a.counts[t] = n;
+        a.counts[t] = n;
         s_rows += n;
         for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
           const uint64_t e = stage[j];
@@ -906,7 +913,6 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         ACC(6);  // row updates
         // carried scalars
         const uint64_t hnew = hand - snib;
-        if (role == 0) h0 = hnew; else if (role == 1) h1 = hnew; else h2 = hnew;
         if (snib) { trick = scat | (svlv << 8); passes = 0; } else { passes += 1; }
         const bool won = hnew == 0;
         const uint32_t o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14
@@ -915,6 +921,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         tr1.x |= (uint32_t)won << 8 | o_reward << 16;
         tr1.w = (uint32_t)idx;
         ply += 1;
+        dnext += 1;
         ACC(7);  // carried scalars
         if (won) {  // auto-reset: next episode of this table
           if (lane == 0) {  // the wave owns its statistics slot: plain read-modify-write
@@ -925,20 +932,23 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           episode += 1;
           uint32_t dk0 = a.k0, dk1 = a.k1;
           asm volatile("" : "+s"(dk0), "+s"(dk1));
+          uint64_t h0, h1, h2;
           deal_wave(gid, episode, dk0, dk1, lane, h0, h1, h2);
+          hc = h1; hn = h2; hp = h0;  // the lord (role 1) moves first, then down (2), then up (0)
           R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
               : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
-          role = 1; ply = 0; trick = mk_info(EMPTY, 0, 1); passes = 0;
+          role = 1; ply = 0; trick = mk_info(EMPTY, 0, 1); passes = 0; dnext = 64;
         } else {
           role = role == 2 ? 0 : role + 1;  // lord -> down -> up, game.py:173-181
+          hc = hn; hn = hp; hp = hnew;
           if (lane == DDZ_F_META) R = make_uint4((uint32_t)role | (0xFFu << 16), my_hi | (ply & 0xFFFF), episode, mw);
         }
         ACC(8);  // deal / turn change
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
         ACC(9);  // state store
       }
-      if (tj && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
-      if (tj) tj += 2 * a.T;
+      if (TRAJ && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
+      if (TRAJ) tj += 2 * a.T;
       ACC(4);  // pick + apply + deal + state/trajectory stores
       __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
     }
@@ -1437,8 +1447,10 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
   a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-  if (ids) hipLaunchKernelGGL(k_rollout<true>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(k_rollout<false>, grid, block, 0, st, a);
+  if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true>), grid, block, 0, st, a);
+  else if (ids) hipLaunchKernelGGL((k_rollout<true, false>), grid, block, 0, st, a);
+  else if (traj) hipLaunchKernelGGL((k_rollout<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_rollout<false, false>), grid, block, 0, st, a);
   e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
   return check_launch();
 }
