@@ -773,7 +773,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     // decode once; afterwards the table's scalars are carried across the iterations
     const uint64_t P = pack_row(R);
     const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
-    const uint32_t mw = rl(R.w, DDZ_F_META), my_hi = my & 0xFFFF0000u;
+    const uint32_t my_hi = my & 0xFFFF0000u;
     int role = mx & 0xFF;
     if (role > 2) role = 0;
     const bool active = ((my >> 16) & 0xFF) && !((mx >> 8) & 0xFF);  // dealt and not done
@@ -825,10 +825,10 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       int n = 0, idx = -1;
       uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, same value in every lane
       uint64_t snib = 0;                  // ... as a nib, its category and value | len << 8
-      uint32_t scat = 0, svlv = 0;
+      uint32_t scat = 0, svlv = 0, ncards = 0;  // ... and its number of cards
       const int lc0 = (int)(info & 0xFF);
-      if (lc0 != EMPTY && (lc0 <= QUADRIC || lc0 == BIGBANG)) {
-        // Two thirds of all plies follow a single, a pair, a triple, a bomb or the rocket.  Their
+      if (lc0 != EMPTY && lc0 <= TRIPLE) {
+        // Two thirds of all plies follow a single, a pair or a triple.  Their
         // legal list is pass + the higher groups of the same size + bombs + rocket
         // (card.py:307-325): one lane per candidate, rows built arithmetically and stored
         // straight into the slab; no record table, no staging.
@@ -837,10 +837,10 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         const int cntr = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
         const uint32_t mlc = (uint32_t)__ballot(cntr >= lc0) & (lc0 == SINGLE ? M15 : M13);
         const uint32_t mq = (uint32_t)__ballot(cntr >= 4) & M13;
-        const bool rocket = lc0 != BIGBANG && ((uint32_t)__ballot(cntr >= 1) & JOKERS) == JOKERS;
+        const bool rocket = ((uint32_t)__ballot(cntr >= 1) & JOKERS) == JOKERS;
         const uint32_t ab = gt_mask(lv0);
-        const uint32_t cand = (lc0 == BIGBANG || lc0 == QUADRIC) ? 0u : (mlc & ab);
-        const uint32_t bombs = lc0 == BIGBANG ? 0u : lc0 == QUADRIC ? (mq & ab) : mq;
+        const uint32_t cand = mlc & ab;
+        const uint32_t bombs = mq;
         const int rr = f_rr;
         // the candidate mask is scalar: bit 0 pass | 1..15 groups | 16..28 bombs | 29 rocket
         const uint32_t okm = 1u | (cand << 1) | (bombs << 16) | (rocket ? 1u << 29 : 0u);
@@ -863,8 +863,8 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
         const int sr = (src < 16 ? src - 1 : src - 16) & 15;
         if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
-        else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); }
-        else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); }
+        else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); ncards = 2; }
+        else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); ncards = scat; }
         ACC(5);  // fast path: list + pick
       } else {
         const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
@@ -893,6 +893,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           snib = (uint64_t)rfl((uint32_t)anib) | ((uint64_t)rfl((uint32_t)(anib >> 32)) << 32);
           scat = rfl(acat);
           svlv = rfl((uint32_t)svl[idx]);
+          ncards = (uint32_t)nib_sum(snib);
         }
         ACC(10);  // generic pick
       }
@@ -902,7 +903,6 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       } else {
         if (snib) {  // a pass (half of all plies) moves no card: only recent_handout and the turn change
           const uint32_t cw3 = c.w & 0x00FFFFFFu;
-          const uint32_t ncards = (uint32_t)nib_sum(snib);
           if (lane == DDZ_F_HAND0 + role) {  // envi.py:39-43, byte-wise (no borrow crosses a byte)
             R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
           } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         } else {
           role = role == 2 ? 0 : role + 1;  // lord -> down -> up, game.py:173-181
           hc = hn; hn = hp; hp = hnew;
-          if (lane == DDZ_F_META) R = make_uint4((uint32_t)role | (0xFFu << 16), my_hi | (ply & 0xFFFF), episode, mw);
+          if (lane == DDZ_F_META) { R.x = (uint32_t)role | (0xFFu << 16); R.y = my_hi | (ply & 0xFFFF); }  // z = episode, w: unchanged
         }
         ACC(8);  // deal / turn change
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
