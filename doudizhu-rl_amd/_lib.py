@@ -6,13 +6,14 @@ never imported from here.)"""
 import ctypes as C
 import os
 
-from .build import LIB as _DEFAULT_LIB
+from .build import LIB as _DEFAULT_LIB, LIB_JK as _JK_LIB
 
-_lib = None
+_libs = {}
 
 SYMBOLS = {
     # name: (restype, argtypes)
     "ddz_abi_version": (C.c_int, []),
+    "ddz_num_actions": (C.c_int, []),
     "ddz_strerror": (C.c_char_p, [C.c_int]),
     "ddz_last_hip_error": (C.c_int, []),
     "ddz_state_bytes": (C.c_int64, [C.c_int64]),
@@ -47,11 +48,12 @@ class DdzError(RuntimeError):
     pass
 
 
-def lib():
-    """Load libddz_hip.so; raises (never falls back) when it is absent."""
-    global _lib
-    if _lib is None:
-        LIB = os.environ.get("DDZ_HIP_LIB") or _DEFAULT_LIB  # override: kernel experiments (tools/variants.py)
+def lib(jk=False):
+    """Load libddz_hip.so (jk=True: libddz_hip_jk.so, the rule set with the 24 joker-kicker rows);
+    raises (never falls back) when it is absent."""
+    jk = bool(jk)
+    if jk not in _libs:
+        LIB = _JK_LIB if jk else (os.environ.get("DDZ_HIP_LIB") or _DEFAULT_LIB)  # override: tools/variants.py
         if not os.path.exists(LIB):
             raise DdzError(
                 f"{LIB} is missing: build it with `python __graft_entry__.py build` "
@@ -63,13 +65,15 @@ def lib():
             fn.argtypes = args
         if L.ddz_abi_version() != 1:
             raise DdzError("libddz_hip.so ABI version mismatch")
-        _lib = L
-    return _lib
+        if L.ddz_num_actions() != (13551 if jk else 13527):
+            raise DdzError(f"{LIB}: unexpected rule set ({L.ddz_num_actions()} actions)")
+        _libs[jk] = L
+    return _libs[jk]
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        L = lib()
+        L = L or lib()
         msg = L.ddz_strerror(rc).decode()
         if rc == -3:
             msg += f" (hipError {L.ddz_last_hip_error()})"

@@ -9,6 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef DDZ_NATIVE_JOKER_KICKERS
+#define DDZ_NATIVE_JOKER_KICKERS 0  // 1: libddz_hip_jk.so, the rule set plus the 24 joker-kicker rows (include/ddz_env.h)
+#endif
+
 namespace ddz {
 
 constexpr uint64_t ONES = 0x1111111111111111ull;
@@ -154,7 +158,7 @@ __device__ inline uint32_t classify(uint64_t nib) {
   if (e3 && !e4) {
     if (!e2 && n1 == n3) {
       if (n3 == 1) return mk_info(THREE_ONE, __builtin_ctz(e3), 1);
-      if (n3 <= 5 && chain(e3) && !(n3 == 2 && e1 == JOKERS))
+      if (n3 <= 5 && chain(e3) && (DDZ_NATIVE_JOKER_KICKERS || !(n3 == 2 && e1 == JOKERS)))
         return mk_info(THREE_ONE_LINE, __builtin_ctz(e3), n3);
     }
     if (!e1 && n2 == n3) {
@@ -164,7 +168,7 @@ __device__ inline uint32_t classify(uint64_t nib) {
     return INFO_INVALID;
   }
   if (n4 == 1 && !e3) {
-    if (!e2 && n1 == 2 && e1 != JOKERS) return mk_info(FOUR_TAKE_ONE, __builtin_ctz(e4), 1);
+    if (!e2 && n1 == 2 && (DDZ_NATIVE_JOKER_KICKERS || e1 != JOKERS)) return mk_info(FOUR_TAKE_ONE, __builtin_ctz(e4), 1);
     if (!e1 && n2 == 2) return mk_info(FOUR_TAKE_TWO, __builtin_ctz(e4), 1);
   }
   return INFO_INVALID;

@@ -106,7 +106,9 @@ constexpr int EM_COUNT = 0;   // nothing (list size only)
 constexpr int EM_WRITE = 1;   // rows (+ids) into the CSR list at base + running index
 constexpr int EM_PICK = 2;    // EM_WRITE + capture the row with list index pk.want
 constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS staging list
-constexpr int STAGE_CAP = 500;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py);
+[[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
+[[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
+constexpr int STAGE_CAP = DDZ_NATIVE_JOKER_KICKERS ? 512 : 500;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py);
                                  // 500 keeps k_rollout's block at 53 KB of LDS = three blocks per CU
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
@@ -388,6 +390,25 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
       n = scan_combos<EM, IDS>(2, 66, ID_FOUR_TAKE_TWO + 66 * q, 4ull << (4 * q), q, 1, 2, FOUR_TAKE_TWO, hot, hand8,
                                lane, o, n, pk);
     }
+#if DDZ_NATIVE_JOKER_KICKERS
+  // optional extension: quad + both jokers (a FOUR_TAKE_ONE) and two consecutive triples + both jokers (a
+  // THREE_ONE_LINE of len 2) -- the vectors server/mcts/get_moves.py:22-34 lists; one lane each, last ids
+  if ((m1 & JOKERS) == JOKERS) {
+    const uint32_t mm = m3 & M12;
+    const uint32_t quads = (LEAD || f.lc == FOUR_TAKE_ONE) ? (m4 & above) : 0u;
+    const uint32_t pairs3 = (LEAD || (f.lc == THREE_ONE_LINE && f.ll == 2)) ? (mm & (mm >> 1) & above) : 0u;
+    if (quads | pairs3) {
+      const bool isq = lane < 13;
+      const int r = isq ? lane : (lane - 13) & 15;
+      const bool ok = isq ? ((quads >> r) & 1u) : (lane < 24 && ((pairs3 >> r) & 1u));
+      const uint64_t jk = (1ull << 52) | (1ull << 56);
+      const uint64_t nib = (isq ? (4ull << (4 * r)) : (0x33ull << (4 * r))) | jk;
+      const int cat = isq ? FOUR_TAKE_ONE : THREE_ONE_LINE;
+      const uint4 row = (EM == EM_WRITE || EM == EM_PICK) ? unpack_row(nib, (uint32_t)cat) : make_uint4(0, 0, 0, 0);
+      n = scan_emit<EM, IDS>(ok, (isq ? ID_JK_FOUR : ID_JK_PLANE) + r, nib, cat, r | ((isq ? 1 : 2) << 8), row, o, n, pk);
+    }
+  }
+#endif
   return n;
 }
 
@@ -1291,6 +1312,7 @@ int ensure_counts(ddz_env* e, hipStream_t st) {
 extern "C" {
 
 int ddz_abi_version(void) { return DDZ_ABI_VERSION; }
+int ddz_num_actions(void) { return DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS; }
 
 const char* ddz_strerror(int code) {
   switch (code) {

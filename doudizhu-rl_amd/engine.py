@@ -46,8 +46,11 @@ class BatchedEnv:
     """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
-                 want_ids=True):
-        self.lib = _lib.lib()
+                 want_ids=True, native_joker_kickers=False):
+        # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
+        # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
+        self.native_joker_kickers = bool(native_joker_kickers)
+        self.lib = _lib.lib(jk=self.native_joker_kickers)
         self.device = _require_gpu(device)
         self.T = int(n_tables)
         if self.T <= 0:
@@ -273,11 +276,12 @@ def rows_to_onehot(rows):
     return out
 
 
-def get_moves(hands, lasts, want_ids=True, row_capacity=None):
+def get_moves(hands, lasts, want_ids=True, row_capacity=None, native_joker_kickers=False):
     """Batched r.get_moves(hand15, last15) (envi.py:111): hands/lasts int8 [n,15|16] on the
     GPU.  Returns (offsets[n+1] i32, rows[total,16] i8, ids[total] i32 | None); one host sync
-    to trim the outputs."""
-    L = _lib.lib()
+    to trim the outputs.  native_joker_kickers: see BatchedEnv."""
+    L = _lib.lib(jk=native_joker_kickers)
+    NUM_ACTIONS = L.ddz_num_actions()
     dev = _require_gpu(hands.device)
 
     def pad(x):

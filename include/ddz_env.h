@@ -23,6 +23,12 @@ extern "C" {
 
 #define DDZ_ABI_VERSION 1
 #define DDZ_NUM_ACTIONS 13527 /* rule_based/utils/card.py:34-159 */
+/* Optional rule-set extension, a second build of the same source (libddz_hip_jk.so,
+ * -DDDZ_NATIVE_JOKER_KICKERS=1; default library: off).  It adds the 24 vectors that card.py:116,142 exclude
+ * but the reference's native r.get_moves is known to return -- server/mcts/get_moves.py:22-34 builds
+ * exactly them ("sidaihuojian": quad + both jokers, 13; "sandaihuojian": two consecutive triples + both
+ * jokers, 11) to filter them out.  Ids 13527 + quad rank (category FOUR_TAKE_ONE) and 13540 + start rank
+ * (category THREE_ONE_LINE, len 2): last in every list.  ddz_num_actions() tells the builds apart.     */
 #define DDZ_ROW 16            /* packed row: int8 counts[15] (3..K,A,2,BJ,CJ; envi.py:122-124) + 1 aux byte */
 #define DDZ_NFIELDS 11
 #define DDZ_TRAJ_BYTES 32
@@ -59,6 +65,7 @@ enum { DDZ_F_HAND0 = 0, DDZ_F_HIST0 = 3, DDZ_F_RECENT0 = 6, DDZ_F_TAKEN = 9, DDZ
 typedef struct ddz_env ddz_env_t;
 
 int ddz_abi_version(void);
+int ddz_num_actions(void); /* 13527 (default) or 13551 (joker-kicker build) */
 const char* ddz_strerror(int code);
 /* last hipError_t seen by this library on the calling thread (0 = hipSuccess) */
 int ddz_last_hip_error(void);

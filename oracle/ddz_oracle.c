@@ -11,7 +11,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define NA DDZO_NUM_ACTIONS
+#ifndef DDZO_NATIVE_JOKER_KICKERS
+#define DDZO_NATIVE_JOKER_KICKERS 0
+#endif
+/* Optional rule-set extension (libddz_oracle_jk.so, default OFF): the 13 "quad + both jokers" and 11
+ * "two consecutive triples + both jokers" vectors that card.py:116,142 exclude but the reference's
+ * native get_moves is known to emit -- server/mcts/get_moves.py:22-34 builds exactly these 24
+ * vectors to filter them out of its result.  They get the ids 13527..13539 (by quad rank) and
+ * 13540..13550 (by start rank), i.e. they come last in every list.  Unverifiable beyond that.    */
+#define NA_BASE DDZO_NUM_ACTIONS
+#define NA (DDZO_NUM_ACTIONS + 24 * DDZO_NATIVE_JOKER_KICKERS)
 #define NR DDZO_NUM_RANKS
 
 static int8_t g_rows[NA][DDZO_ROW]; /* counts + category in byte 15 */
@@ -154,11 +163,24 @@ void ddzo_init(void) {
       if (r != main) rem[nrem++] = r;
     combos(rem, nrem, 2, c, 2, DDZO_FOUR_TAKE_TWO, main, 1, 0);
   }
+  if (g_n != NA_BASE) abort();
+#if DDZO_NATIVE_JOKER_KICKERS
+  for (int main = 0; main < 13; ++main) { /* sidaihuojian, server/mcts/get_moves.py:22-27 */
+    memcpy(c, z, sizeof c); c[main] = 4; c[13] = c[14] = 1;
+    push(c, DDZO_FOUR_TAKE_ONE, main, 1);
+  }
+  for (int s = 0; s < 11; ++s) { /* sandaihuojian, server/mcts/get_moves.py:29-34 */
+    memcpy(c, z, sizeof c); c[s] = c[s + 1] = 3; c[13] = c[14] = 1;
+    push(c, DDZO_THREE_ONE_LINE, s, 2);
+  }
+#endif
   if (g_n != NA) abort();
   for (int i = 0; i < NA; ++i) g_sorted[i] = i;
   qsort(g_sorted, NA, sizeof(int32_t), cmp_pk);
   g_ready = 1;
 }
+
+int ddzo_num_actions(void) { return NA; }
 
 void ddzo_action_table(int8_t* rows, uint8_t* info) {
   ddzo_init();

@@ -18,25 +18,48 @@ TR_BYTES = 32
 STEP_RANDOM, STEP_CHOICE, STEP_ROWS = 0, 1, 2
 PLANES = (4, 7, 9, 6)
 
-_lib = None
+_libs = {}
+_jk = False  # which rule set lib() serves: False = card.py (13,527 rows), True = + the 24 joker-kicker rows
 
 
-def build(force=False):
-    so = os.path.join(HERE, "libddz_oracle.so")
+def build(force=False, jk=False):
+    name = "libddz_oracle_jk.so" if jk else "libddz_oracle.so"
+    so = os.path.join(HERE, name)
     src = os.path.join(HERE, "ddz_oracle.c")
     hdr = os.path.join(HERE, "ddz_oracle.h")
     stale = (not os.path.exists(so)) or any(
         os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
     if force or stale:
-        subprocess.check_call(["make", "-C", HERE, "libddz_oracle.so"],
+        subprocess.check_call(["make", "-C", HERE, name],
                               stdout=subprocess.DEVNULL)
     return so
 
 
+class variant:
+    """`with oracle.variant(jk=True):` -- every call inside uses the rule set with the 24 extra
+    joker-kicker rows (oracle/ddz_oracle.c, DDZO_NATIVE_JOKER_KICKERS)."""
+
+    def __init__(self, jk):
+        self.jk = bool(jk)
+
+    def __enter__(self):
+        global _jk
+        self.prev, _jk = _jk, self.jk
+        return self
+
+    def __exit__(self, *exc):
+        global _jk
+        _jk = self.prev
+
+
+def num_actions():
+    return int(lib().ddzo_num_actions())
+
+
 def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(build())
+    if _jk not in _libs:
+        L = C.CDLL(build(jk=_jk))
+        L.ddzo_num_actions.restype = C.c_int
         p = C.c_void_p
         L.ddzo_init.restype = None
         L.ddzo_action_table.argtypes = [p, p]
@@ -60,8 +83,8 @@ def lib():
         L.ddzo_rollout_random.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, p, p]
         L.ddzo_rollout_random.restype = C.c_int64
         L.ddzo_init()
-        _lib = L
-    return _lib
+        _libs[_jk] = L
+    return _libs[_jk]
 
 
 def _ptr(a):
@@ -69,8 +92,8 @@ def _ptr(a):
 
 
 def action_table():
-    rows = np.zeros((NUM_ACTIONS, ROW), np.int8)
-    info = np.zeros((NUM_ACTIONS, 4), np.uint8)
+    rows = np.zeros((num_actions(), ROW), np.int8)
+    info = np.zeros((num_actions(), 4), np.uint8)
     lib().ddzo_action_table(_ptr(rows), _ptr(info))
     return rows, info
 
@@ -88,8 +111,8 @@ def legal(hand15, last15=None):
     """sorted canonical ids of get_mask(hand, action_space, last)."""
     h = np.ascontiguousarray(hand15, np.int8)
     l = None if last15 is None else np.ascontiguousarray(last15, np.int8)
-    ids = np.zeros(NUM_ACTIONS, np.int32)
-    n = lib().ddzo_legal(_ptr(h), _ptr(l), _ptr(ids), NUM_ACTIONS)
+    ids = np.zeros(num_actions(), np.int32)
+    n = lib().ddzo_legal(_ptr(h), _ptr(l), _ptr(ids), len(ids))
     if n < 0:
         raise ValueError("last is not a combo of the action space (or bad hand)")
     return ids[:n].copy()

@@ -532,3 +532,74 @@ def test_dqn_training_example_runs(pkg):
     out = mod.main(["--tables", "256", "--iters", "60"])
     assert out["status"] == 0 and out["replay"] > 256 and out["episodes"] > 0
     assert out["last_loss"] is not None and np.isfinite(out["last_loss"])
+
+
+def _joker_hands(rng, n, cards):
+    """hands that hold both jokers and are rich in quads / adjacent triples"""
+    hands = _plane_rich_hands(rng, n, cards - 2)
+    hands[:, 13:] = 0
+    for i in range(n):
+        while hands[i].sum() > cards - 2:
+            r = rng.choice(np.flatnonzero(hands[i, :13] > 0))
+            hands[i, r] -= 1
+        while hands[i].sum() < cards - 2:
+            r = rng.choice(np.flatnonzero(hands[i, :13] < 4))
+            hands[i, r] += 1
+    hands[:, 13:] = 1
+    return hands
+
+
+def test_joker_kicker_build_vs_oracle(pkg, oracle):
+    """The optional rule set (24 extra rows, default off): lists of the jk library == jk oracle, as lead,
+    as follow of an ordinary FOUR_TAKE_ONE / 2-plane and as follow of one of the extra rows; lock-step
+    episodes stay bit-identical; the default library never emits an extra id."""
+    rng = np.random.default_rng(77)
+    n = 400
+    hands = _joker_hands(rng, n, 20)
+    with oracle.variant(jk=True):
+        rows_t, info_t = oracle.action_table()
+        lasts = np.zeros((n, 15), np.int8)
+        pools = {13: np.flatnonzero(info_t[:, 0] == 13), 10: np.flatnonzero((info_t[:, 0] == 10) & (info_t[:, 2] == 2))}
+        for i in range(n):
+            if i % 4 == 1:
+                lasts[i] = rows_t[rng.choice(pools[13][pools[13] < 13527][:400]), :15]
+            elif i % 4 == 2:
+                lasts[i] = rows_t[rng.choice(pools[10][pools[10] < 13527][:300]), :15]
+            elif i % 4 == 3:
+                lasts[i] = rows_t[rng.integers(13527, 13551), :15]   # an extra row was played
+        offsets, rows, ids = pkg.get_moves(torch.from_numpy(hands).to(_dev()), torch.from_numpy(lasts).to(_dev()),
+                                           native_joker_kickers=True)
+        offsets, rows, ids = offsets.cpu().numpy(), rows.cpu().numpy(), ids.cpu().numpy()
+        extras = 0
+        for i in range(n):
+            want = oracle.legal(hands[i], lasts[i] if lasts[i].any() else None)
+            got = ids[offsets[i]:offsets[i + 1]]
+            assert np.array_equal(got, want), (i, hands[i], lasts[i])
+            assert np.array_equal(rows[offsets[i]:offsets[i + 1], :15], rows_t[want, :15])
+            assert np.array_equal(rows[offsets[i]:offsets[i + 1], 15].astype(np.uint8), info_t[want, 0])
+            extras += int((want >= 13527).sum())
+        assert extras > 200
+        # lock-step env parity under the extension (state, lists, results every iteration)
+        T = 256
+        env = pkg.BatchedEnv(T, seed=9, device=_dev(), native_joker_kickers=True)
+        ref = oracle.OracleEnv(T, seed=9)
+        env.reset(); ref.reset()
+        seen = 0
+        for it in range(150):
+            off, rws, idz = env.legal()
+            ref.legal()
+            tot = int(off[-1])
+            assert np.array_equal(off.cpu().numpy(), ref.offsets)
+            assert np.array_equal(idz[:tot].cpu().numpy(), ref.ids[:tot])
+            seen += int((ref.ids[:tot] >= 13527).sum())
+            done, r, _ = env.step(None, pkg.STEP_RANDOM, auto_reset=True)
+            rdone, rr = ref.step(oracle.STEP_RANDOM, auto_reset=True)[:2]
+            assert np.array_equal(done.cpu().numpy(), rdone) and np.array_equal(r.cpu().numpy(), rr)
+        assert np.array_equal(env.state_export().cpu().numpy(), ref.state)
+        env2 = pkg.BatchedEnv(T, seed=9, device=_dev(), native_joker_kickers=True)
+        env2.reset()
+        env2.rollout_random(150)
+        assert torch.equal(env2.state_export(), env.state_export()) and env2.status() == 0
+    # default library: same hands, no id of the extension
+    _, _, ids0 = pkg.get_moves(torch.from_numpy(hands).to(_dev()), torch.zeros((n, 15), dtype=torch.int8, device=_dev()))
+    assert int(ids0.max()) < 13527

@@ -12,8 +12,8 @@ DRIVER = r"""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 from oracle import oracle
-oracle._lib = None
-oracle.build = lambda force=False: sys.argv[2]          # load the sanitizer build instead
+oracle._libs.clear()
+oracle.build = lambda force=False, jk=False: sys.argv[2]   # load the sanitizer build instead
 rows, info = oracle.action_table()
 g = np.load(sys.argv[1] + "/tests/golden/legal_cases.npz")
 for k in range(0, len(g["hands"]), 7):
