@@ -415,7 +415,7 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
 
 // lead and follow are separate instantiations: on lead every gate is true at compile time
 template <int EM, bool IDS, class HT>
-__device__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
+__device__ __forceinline__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
   const Follow f = follow_of(info);
   return f.lead ? plan_scan_t<EM, IDS, true>(hand, f, hot, lane, o, pk) : plan_scan_t<EM, IDS, false>(hand, f, hot, lane, o, pk);
