@@ -1123,22 +1123,46 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nslo
 // face: f32 [T][P][15][4], one thread per (table, plane, rank) -> one 16-byte store.
 // plane kinds: 0 hand 1 taken 2..4 history of (role-1, role, role+1) 5,6 recent handout of
 // (role-1, role-2) 7,8 prob planes (spec v1; native get_state_prob is absent).
-__constant__ uint8_t c_face_kind[4][9] = {{0, 1, 7, 8, 0, 0, 0, 0, 0},
-                                          {0, 1, 2, 3, 4, 7, 8, 0, 0},
-                                          {0, 1, 2, 3, 4, 5, 6, 7, 8},
-                                          {0, 1, 5, 6, 7, 8, 0, 0, 0}};
+// variant 0: {0,1,7,8}  1: {0,1,2,3,4,7,8}  2: {0,..,8}  3: {0,1,5,6,7,8}   (envi.py:87-96,165-217)
 
-__global__ __launch_bounds__(BLOCK) void k_observe(const uint8_t* __restrict__ state, int64_t T, int variant,
-                                                   int P, float4* __restrict__ out) {
+// write-once output streams (`face`, thermometer planes): nontemporal 16-byte stores.  Measured on k_observe
+// at 524,288 tables (0.6-1.2 GB per call): 3.1 TB/s with plain stores, 5.3-5.7 TB/s with these.
+__device__ __forceinline__ void store_stream(float4* p, const float4 v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z);
+  __builtin_nontemporal_store(v.w, &p->w);
+}
+
+// VARIANT is a template parameter: the divisions by P * 15 and by 15 are by constants (a 64-bit runtime
+// division per 16-byte store made the first version instruction-bound at half the HBM write rate) and the
+// plane kinds are immediates.
+template <int VARIANT>
+__global__ __launch_bounds__(BLOCK) void k_observe(const uint8_t* __restrict__ state, int64_t T,
+                                                   float4* __restrict__ out) {
+  constexpr int P = VARIANT == 0 ? 4 : VARIANT == 1 ? 7 : VARIANT == 2 ? 9 : 6;
+  // kinds of the planes, 4 bits each, plane 0 in the low nibble
+  constexpr uint64_t KINDS = VARIANT == 0 ? 0x8710ull : VARIANT == 1 ? 0x8743210ull
+                           : VARIANT == 2 ? 0x876543210ull : 0x876510ull;
   const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (idx >= T * P * 15) return;
-  const int64_t t = idx / (P * 15);
-  const int rem = (int)(idx - t * (P * 15)), p = rem / 15, i = rem - p * 15;
-  auto byte = [&](int f, int k) { return (int)state[t * STATE_ROW_BYTES + f * 16 + k]; };
+  if (idx >= T * (P * 15)) return;
+  int64_t t;
+  int rem;
+  if (T * (P * 15) <= 0x7FFFFFFFll) {  // wave-uniform: 32-bit index arithmetic
+    const uint32_t i32 = (uint32_t)idx, t32 = i32 / (uint32_t)(P * 15);
+    t = t32;
+    rem = (int)(i32 - t32 * (uint32_t)(P * 15));
+  } else {
+    t = idx / (P * 15);
+    rem = (int)(idx - t * (P * 15));
+  }
+  const int p = rem / 15, i = rem - p * 15;
+  const uint8_t* row = state + t * STATE_ROW_BYTES;
+  auto byte = [&](int f, int k) { return (int)row[f * 16 + k]; };
   int role = byte(DDZ_F_META, 0);
   if (role > 2) role = 0;
-  const int kind = c_face_kind[variant][p];
-  const int rm1 = (role + 2) % 3, rp1 = (role + 1) % 3;
+  const int kind = (int)((KINDS >> (4 * p)) & 15);
+  const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
   float4 v;
   if (kind < 7) {
     const int f = kind == 0 ? DDZ_F_HAND0 + role : kind == 1 ? DDZ_F_TAKEN
@@ -1153,7 +1177,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(const uint8_t* __restrict__ s
     auto slot = [&](int j) { return (j >= known && j < total) ? fr : 0.f; };
     v = make_float4(slot(0), slot(1), slot(2), slot(3));
   }
-  out[idx] = v;
+  store_stream(&out[idx], v);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_onehot(const uint8_t* __restrict__ rows, int64_t n,
@@ -1162,7 +1186,7 @@ __global__ __launch_bounds__(BLOCK) void k_onehot(const uint8_t* __restrict__ ro
   if (idx >= n * 15) return;
   const int64_t r = idx / 15;
   const int c = rows[r * 16 + (idx - r * 15)];
-  out[idx] = make_float4(c > 0 ? 1.f : 0.f, c > 1 ? 1.f : 0.f, c > 2 ? 1.f : 0.f, c > 3 ? 1.f : 0.f);
+  store_stream(&out[idx], make_float4(c > 0 ? 1.f : 0.f, c > 1 ? 1.f : 0.f, c > 2 ? 1.f : 0.f, c > 3 ? 1.f : 0.f));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1422,8 +1446,14 @@ int ddz_observe(ddz_env_t* e, int variant, float* face, void* stream) {
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   const int64_t n = e->T * P * 15;
-  hipLaunchKernelGGL(k_observe, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
-                     (const uint8_t*)e->state, e->T, variant, P, (float4*)face);
+  const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK)), block(BLOCK);
+  const uint8_t* st = (const uint8_t*)e->state;
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(k_observe<0>, grid, block, 0, (hipStream_t)stream, st, e->T, (float4*)face); break;
+    case 1: hipLaunchKernelGGL(k_observe<1>, grid, block, 0, (hipStream_t)stream, st, e->T, (float4*)face); break;
+    case 2: hipLaunchKernelGGL(k_observe<2>, grid, block, 0, (hipStream_t)stream, st, e->T, (float4*)face); break;
+    default: hipLaunchKernelGGL(k_observe<3>, grid, block, 0, (hipStream_t)stream, st, e->T, (float4*)face); break;
+  }
   return check_launch();
 }
 
