@@ -39,7 +39,7 @@ constexpr int TB = WPB * 64;     // threads per block of k_table
 constexpr int STATE_ROW_BYTES = DDZ_NFIELDS * DDZ_ROW;  // 176
 
 // k_table phases
-constexpr int F_ENUM = 1, F_STEP = 2, F_RESET = 4, F_COUNT = 8;
+constexpr int F_ENUM = 1, F_STEP = 2, F_RESET = 4, F_COUNT = 8, F_SLAB = 16;
 
 // ------------------------------------------------------------------------------------
 // scratch layout (caller-owned, zero-filled at create)
@@ -501,12 +501,17 @@ struct TableArgs {
   int64_t* blk_stats;
   int32_t* status;
   int64_t* legal_rows;
+  int32_t* slab_counts;      // F_SLAB: [T] list sizes; table t owns rows[t * stride ...] (no cross-table scan)
+  int64_t stride;
 };
 
 template <int FLAGS, int MODE, bool IDS>
 __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   constexpr bool ENUM = FLAGS & F_ENUM, STEP = FLAGS & F_STEP, RESET = FLAGS & F_RESET;
-  constexpr bool COUNT = (FLAGS & (F_STEP | F_RESET | F_COUNT)) != 0;
+  // F_SLAB: the lists live in fixed-stride slabs, so a launch applies the selections to the lists of the
+  // previous launch AND writes the lists of the new state: one launch per lock-step iteration, no CSR scan
+  constexpr bool SLAB = (FLAGS & F_SLAB) != 0;
+  constexpr bool COUNT = !SLAB && (FLAGS & (F_STEP | F_RESET | F_COUNT)) != 0;
   constexpr bool PICK = ENUM && STEP && MODE == DDZ_STEP_RANDOM;
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   int cnt_l = 0;      // lane i: size of the current list of table t0 + i
   int new_cnt_l = 0;  // lane i: size of the next list of table t0 + i
   int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
+  int64_t slab_rows = 0;
   // all independent global loads of the prologue are issued before anything waits
   int part = 0, loc0 = 0;
   uint4 Rnext = make_uint4(0, 0, 0, 0);
@@ -526,6 +532,17 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     for (int j = lane; j < (int)blockIdx.x; j += 64) part += a.cur_blk[j];
     loc0 = a.cur_local[t0];
     if (lane < ntab) cnt_l = a.cur_counts[t0 + lane];
+  }
+  uint4 pre_row = make_uint4(0, 0, 0, 0);  // F_SLAB + CHOICE: lane i prefetches the selected row of table t0 + i
+  int pre_idx = -1;
+  if (SLAB && STEP && lane < ntab) {
+    cnt_l = a.slab_counts[t0 + lane];
+    if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
+    if (MODE == DDZ_STEP_CHOICE) {
+      pre_idx = ((const int32_t*)a.sel)[t0 + lane];
+      if (pre_idx < 0 || pre_idx >= cnt_l) pre_idx = -1;
+      if (pre_idx >= 0) pre_row = a.rows[(t0 + lane) * a.stride + pre_idx];
+    }
   }
   hot_fill<TB>(hot);
   __syncthreads();
@@ -567,11 +584,14 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     if (STEP) {
       int64_t off = base;
       int A = cnt;
-      if (!ENUM) {
+      if (SLAB) {
+        off = t * a.stride;
+        A = (int)rl((uint32_t)cnt_l, i);
+      } else if (!ENUM) {
         off = a.offsets[t];
         A = a.offsets[t + 1] - (int32_t)off;
       }
-      if (off < 0 || off + A > a.cap) A = 0;  // list was truncated: nothing to pick from
+      if (!SLAB && (off < 0 || off + A > a.cap)) A = 0;  // list was truncated: nothing to pick from
       const bool frozen = !active || A <= 0;
       int idx = -1;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen row, wave-uniform
@@ -584,8 +604,12 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
             idx = (int)__umulhi(rfl(d.x), (uint32_t)A);
           }
         } else if (MODE == DDZ_STEP_CHOICE) {
-          idx = ((const int32_t*)a.sel)[t];
-          if (idx < 0 || idx >= A) idx = -1;
+          if (SLAB) {
+            idx = (int)rl((uint32_t)pre_idx, i);
+          } else {
+            idx = ((const int32_t*)a.sel)[t];
+            if (idx < 0 || idx >= A) idx = -1;
+          }
         } else {  // wave-parallel search of the segment for the wanted counts
           const uint4 want = ((const uint4*)a.sel)[t];
           for (int j0 = 0; j0 < A && idx < 0; j0 += 64) {
@@ -598,7 +622,9 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
             if (hb) idx = j0 + __builtin_ctzll(hb);
           }
         }
-        if (idx >= 0 && !PICK) {
+        if (idx >= 0 && SLAB && MODE == DDZ_STEP_CHOICE) {
+          c0 = rl(pre_row.x, i); c1 = rl(pre_row.y, i); c2 = rl(pre_row.z, i); c3 = rl(pre_row.w, i);
+        } else if (idx >= 0 && !PICK) {
           const uint4 r = a.rows[off + idx];
           c0 = rfl(r.x); c1 = rfl(r.y); c2 = rfl(r.z); c3 = rfl(r.w);
         }
@@ -668,7 +694,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     }
     if (changed) {
       if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
-      if (COUNT) {                             // query of the new actor
+      if (COUNT || SLAB) {                     // query of the new actor
         P = pack_row(R);
         const int q1 = role == 0 ? 2 : role - 1, q2 = role == 2 ? 0 : role + 1;
         hand = rl64(P, DDZ_F_HAND0 + role);
@@ -682,11 +708,28 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       const int c = (dealt && !is_done) ? plan_scan<EM_COUNT, false>(hand, info, hot, lane, none, nopk) : 0;
       if (lane == i) new_cnt_l = c;
     }
+    if (SLAB) {  // the list of the (new) state, straight into the table's slab
+      const int64_t sb = t * a.stride;
+      const Out o{a.rows, a.ids, sb, sb + a.stride, nullptr, nullptr, nullptr};
+      Pick nopk{-1, 0, 0, 0, 0};
+      int n = (dealt && !is_done) ? plan_scan<EM_WRITE, IDS>(hand, info, hot, lane, o, nopk) : 0;
+      if (n > a.stride) {  // cannot happen for a <= 20-card hand with the default stride
+        if (lane == 0) atomicOr(a.status, 2);
+        n = 0;
+      }
+      if (lane == 0) a.slab_counts[t] = n;
+      slab_rows += n;
+    }
     base += cnt;
   }
   if (ENUM && ntab > 0 && t0 + ntab == a.T && lane == 0) {
     a.offsets[a.T] = (int32_t)base;
     *a.legal_rows += base;
+  }
+  if (SLAB && ntab > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
+    int64_t* ws = a.blk_stats + 4 * ((int64_t)blockIdx.x * WPB + wv);
+    if (STEP) { ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); }
+    ws[3] += slab_rows;
   }
   if (COUNT) {
     __shared__ int sh[WPB][4];
@@ -1300,6 +1343,8 @@ struct Io {  // optional buffers of one k_table launch
   int8_t* reward = nullptr;
   uint8_t* illegal = nullptr;
   uint8_t* traj = nullptr;
+  int32_t* slab_counts = nullptr;
+  int64_t stride = 0;
 };
 
 template <int FLAGS, int MODE>
@@ -1314,13 +1359,16 @@ int launch_table(ddz_env* e, const Io& io, hipStream_t st) {
   a.nxt_counts = e->sc.counts[nxt]; a.nxt_local = e->sc.local_off[nxt]; a.nxt_blk = e->sc.blk_tot[nxt];
   a.done = io.done; a.reward = io.reward; a.illegal = io.illegal; a.traj = (uint4*)io.traj;
   a.blk_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
+  a.slab_counts = io.slab_counts; a.stride = io.stride;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-  if ((FLAGS & F_ENUM) && io.ids)
+  if ((FLAGS & (F_ENUM | F_SLAB)) && io.ids)
     hipLaunchKernelGGL((k_table<FLAGS, MODE, true>), grid, block, 0, st, a);
   else
     hipLaunchKernelGGL((k_table<FLAGS, MODE, false>), grid, block, 0, st, a);
   int rc = check_launch();
-  if (rc == DDZ_OK && (FLAGS & (F_STEP | F_RESET | F_COUNT))) {
+  if (rc == DDZ_OK && (FLAGS & F_SLAB)) {
+    if (FLAGS & F_STEP) e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
+  } else if (rc == DDZ_OK && (FLAGS & (F_STEP | F_RESET | F_COUNT))) {
     e->parity = nxt;
     e->counts_valid = true;
   }
@@ -1436,6 +1484,34 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
     case DDZ_STEP_RANDOM: return launch_table<F_STEP, DDZ_STEP_RANDOM>(e, io, st);
     case DDZ_STEP_CHOICE: return launch_table<F_STEP, DDZ_STEP_CHOICE>(e, io, st);
     default: return launch_table<F_STEP, DDZ_STEP_ROWS>(e, io, st);
+  }
+}
+
+int ddz_legal_slab(ddz_env_t* e, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!counts || !rows || stride <= 0) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  Io io;
+  io.rows = rows; io.ids = ids; io.slab_counts = counts; io.stride = stride;
+  return launch_table<F_SLAB, 0>(e, io, (hipStream_t)stream);
+}
+
+int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
+                  int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_ROWS || !counts || !rows || stride <= 0) return DDZ_EINVAL;
+  if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  Io io;
+  io.sel = sel; io.rows = rows; io.ids = ids; io.slab_counts = counts; io.stride = stride;
+  io.auto_reset = auto_reset ? 1 : 0; io.done = done; io.reward = reward; io.illegal = illegal; io.traj = traj;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case DDZ_STEP_RANDOM: return launch_table<F_STEP | F_SLAB, DDZ_STEP_RANDOM>(e, io, st);
+    case DDZ_STEP_CHOICE: return launch_table<F_STEP | F_SLAB, DDZ_STEP_CHOICE>(e, io, st);
+    default: return launch_table<F_STEP | F_SLAB, DDZ_STEP_ROWS>(e, io, st);
   }
 }
 

@@ -71,7 +71,7 @@ class BatchedEnv:
         self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self._stats = torch.zeros(8, dtype=torch.int64, device=d)
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
         h = C.c_void_p()
         check(self.lib.ddz_create(C.byref(h), self.T, self.seed, self.table_id_base, d.index,
                                   _p(self.state), self.state.numel(), _p(self.scratch),
@@ -108,7 +108,7 @@ class BatchedEnv:
             if mask.numel() != self.T:
                 raise ValueError("mask must have one byte per table")
         check(self.lib.ddz_reset(self._h, _p(mask), _stream(self.device)))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
 
     def legal(self):
         """CSR legal-move lists of all tables (envi.py:98-116 valid_actions(tensor=False)).
@@ -116,7 +116,7 @@ class BatchedEnv:
         offsets[T] rows are meaningful.  No host sync."""
         check(self.lib.ddz_legal(self._h, _p(self.offsets), _p(self.rows), _p(self.ids), self.cap,
                                  _stream(self.device)))
-        self._legal_fresh = True
+        self._legal_fresh, self._slab_fresh = True, False  # legal() packed CSR rows into the row buffer
         return self.offsets, self.rows, self.ids
 
     def _need_legal(self):
@@ -146,7 +146,7 @@ class BatchedEnv:
                                 _p(self.offsets), _p(self.rows), int(bool(auto_reset)),
                                 _p(self.done), _p(self.reward), _p(self.illegal), _p(traj),
                                 _stream(self.device)))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
         return self.done, self.reward, self.illegal
 
     def step_onehot(self, actions, auto_reset=True, traj=None):
@@ -204,6 +204,45 @@ class BatchedEnv:
         st = self.slab_stride
         return None if self.ids is None else self.ids[: self.T * st].view(self.T, st)
 
+    def legal_slab(self):
+        """Legal-move lists of all tables in the slab layout: (counts[T] i32, rows [T,stride,16] i8,
+        ids [T,stride] i32 | None); table t's moves are rows[t, :counts[t]] in ascending canonical id.
+        No cross-table prefix, so step_slab() can apply the choices AND write the next lists in one launch."""
+        if self.slab_stride < MAX_LEGAL_PER_TABLE:
+            raise ValueError(f"slab lists need row_capacity >= {MAX_LEGAL_PER_TABLE} * n_tables")
+        check(self.lib.ddz_legal_slab(self._h, _p(self.counts), _p(self.rows), _p(self.ids), self.slab_stride,
+                                      _stream(self.device)))
+        self._legal_fresh = False  # the CSR buffers (offsets) do not describe the row buffer any more
+        self._slab_fresh = True
+        return self.counts, self.slab_rows(), self.slab_ids()
+
+    def step_slab(self, sel=None, mode=STEP_CHOICE, auto_reset=True, traj=None):
+        """One lock-step iteration in ONE launch: apply `sel` (STEP_CHOICE: int32[T] index into each
+        table's slab list; STEP_ROWS: int8[T,16]; STEP_RANDOM: engine RNG) to the lists legal_slab() /
+        the previous step_slab() left in the buffers, then overwrite them with the lists of the new
+        states (game.py:95-106 + envi.py:98-116).  Returns (done, r, illegal) like step()."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        if mode == STEP_CHOICE:
+            sel = sel.to(device=self.device, dtype=torch.int32).contiguous()
+            if sel.numel() != self.T:
+                raise ValueError("choice must have one index per table")
+        elif mode == STEP_ROWS:
+            sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
+            if tuple(sel.shape) != (self.T, ROW):
+                raise ValueError("rows must be [T,16] int8")
+        elif mode != STEP_RANDOM:
+            raise ValueError("bad step mode")
+        if traj is not None and (traj.dtype != torch.uint8 or traj.numel() != self.T * TRAJ_BYTES
+                                 or not traj.is_contiguous()):
+            raise ValueError("traj must be a contiguous uint8 [T,32] tensor")
+        check(self.lib.ddz_step_slab(self._h, mode, _p(sel) if mode != STEP_RANDOM else None, _p(self.counts),
+                                     _p(self.rows), _p(self.ids), self.slab_stride, int(bool(auto_reset)),
+                                     _p(self.done), _p(self.reward), _p(self.illegal), _p(traj),
+                                     _stream(self.device)))
+        self._legal_fresh, self._slab_fresh = False, True  # the buffers hold the lists of the new states
+        return self.done, self.reward, self.illegal
+
     def rollout_random(self, n_iters, traj=None):
         """n_iters lock-step iterations of {legal list, step_random(auto_reset)}
         (game.py:169-181 with envi.py:79-85), one kernel launch each.  The lists of the last
@@ -216,7 +255,7 @@ class BatchedEnv:
         check(self.lib.ddz_rollout_random(self._h, int(n_iters), _p(self.counts), _p(self.rows),
                                           _p(self.ids), self.slab_stride, _p(self._stats), _p(traj),
                                           _stream(self.device)))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
 
     def rollout_random_csr(self, n_iters, traj=None):
         """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them); one
@@ -227,7 +266,7 @@ class BatchedEnv:
             raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
         check(self.lib.ddz_rollout_random_csr(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
                                               _p(self.ids), self.cap, _p(traj), _stream(self.device)))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
 
     def rollout_random_timed(self, n_iters):
         """Same loop between two hipEvents; returns the elapsed ms of the n_iters launches.
@@ -236,7 +275,7 @@ class BatchedEnv:
         check(self.lib.ddz_rollout_random_timed(self._h, int(n_iters), _p(self.counts), _p(self.rows),
                                                 _p(self.ids), self.slab_stride, ms,
                                                 _stream(self.device)))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
         return ms[0]
 
     def stats(self):
@@ -261,7 +300,7 @@ class BatchedEnv:
             raise ValueError("state size mismatch")
         self.state.copy_(state.to(self.device).view(-1))
         check(self.lib.ddz_invalidate(self._h))
-        self._legal_fresh = False
+        self._legal_fresh = self._slab_fresh = False
 
 
 def rows_to_onehot(rows):

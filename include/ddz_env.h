@@ -109,6 +109,18 @@ int ddz_step(ddz_env_t* env, int mode, const void* sel, const int32_t* offsets,
              const int8_t* rows, int auto_reset, uint8_t* done, int8_t* reward,
              uint8_t* illegal, uint8_t* traj, void* stream);
 
+/* Slab variant of ddz_legal / ddz_step (fixed-stride list layout, as ddz_rollout_random uses): table t owns
+ * rows[t * stride ... t * stride + counts[t]).  Without the CSR prefix there is no dependency between tables,
+ * so ONE launch per lock-step iteration does both halves of the reference's loop body (game.py:95-106 +
+ * envi.py:98-116): ddz_step_slab applies the selections -- indices into (CHOICE) or rows of (ROWS) the lists that
+ * are in the buffers -- and overwrites them with the lists of the new states.  ddz_legal_slab fills the buffers
+ * for the current states (after ddz_reset / ddz_create / a state import).  stride >= 512 holds any list of a
+ * <= 20-card hand; a list that does not fit raises status bit 1 and is reported empty.                       */
+int ddz_legal_slab(ddz_env_t* env, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride, void* stream);
+int ddz_step_slab(ddz_env_t* env, int mode, const void* sel, int32_t* counts, int8_t* rows, int32_t* ids,
+                  int64_t stride, int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj,
+                  void* stream);
+
 /* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
 int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
 

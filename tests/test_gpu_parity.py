@@ -603,3 +603,62 @@ def test_joker_kicker_build_vs_oracle(pkg, oracle):
     # default library: same hands, no id of the extension
     _, _, ids0 = pkg.get_moves(torch.from_numpy(hands).to(_dev()), torch.zeros((n, 15), dtype=torch.int8, device=_dev()))
     assert int(ids0.max()) < 13527
+
+
+@pytest.mark.parametrize("T,iters,seed,base", [(700, 220, 3, 0), (4096, 60, 11, 2**40)])
+def test_slab_api_lockstep_vs_oracle(pkg, oracle, T, iters, seed, base):
+    """legal_slab / step_slab (one launch per iteration) vs the oracle's legal / step with the same
+    choices: lists (sizes, ids, rows), done / r / illegal and the full state every iteration; CHOICE with
+    valid, out-of-range and negative indices, ROWS every few iterations, no auto-reset on some of them."""
+    rng = np.random.default_rng(seed)
+    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), table_id_base=base)
+    ref = oracle.OracleEnv(T, seed=seed, gid_base=base)
+    env.reset(); ref.reset()
+    counts, rows, ids = env.legal_slab()
+    for it in range(iters):
+        roff, rrows, rids = ref.legal()
+        n = np.diff(roff)
+        c = counts.cpu().numpy()
+        assert np.array_equal(c, n)
+        idn = ids.cpu().numpy(); rwn = rows.cpu().numpy()
+        take = np.arange(env.slab_stride)[None, :] < n[:, None]
+        assert np.array_equal(idn[take], rids)
+        assert np.array_equal(rwn[take], rrows)
+        choice = (rng.random(T) * np.maximum(n, 1)).astype(np.int32)
+        bad = rng.random(T) < 0.03
+        choice[bad] = np.where(rng.random(bad.sum()) < 0.5, -1, n[bad] + rng.integers(0, 3, bad.sum()))
+        auto = it % 5 != 4
+        if it % 7 == 3:   # ROWS: the chosen rows themselves (bad ones: a row that is not in the list)
+            ok = (choice >= 0) & (choice < n)
+            sel_rows = np.zeros((T, 16), np.int8)
+            sel_rows[ok] = rrows[roff[:-1][ok] + choice[ok]]
+            sel_rows[~ok, 0] = 7
+            done, r, ill = env.step_slab(torch.from_numpy(sel_rows).to(_dev()), pkg.STEP_ROWS, auto_reset=auto)
+            rdone, rr, rill, _ = ref.step(oracle.STEP_ROWS, sel_rows, auto_reset=auto)
+        else:
+            done, r, ill = env.step_slab(torch.from_numpy(choice).to(_dev()), pkg.STEP_CHOICE, auto_reset=auto)
+            rdone, rr, rill, _ = ref.step(oracle.STEP_CHOICE, choice, auto_reset=auto)
+        assert np.array_equal(done.cpu().numpy(), rdone) and np.array_equal(r.cpu().numpy(), rr)
+        assert np.array_equal(ill.cpu().numpy(), rill)
+        assert np.array_equal(env.state_export().cpu().numpy(), ref.state)
+        if it % 20 == 19:  # finished tables stay frozen without auto-reset until reset(mask)
+            m = (env.field(10)[:, 1] != 0)
+            env.reset(mask=m); ref.reset(m.cpu().numpy().astype(np.uint8))
+            counts, rows, ids = env.legal_slab()
+    assert env.status() == 0
+    st = env.stats()
+    assert st["plies"] > 0 and st["episodes"] > 0
+
+
+def test_slab_api_random_equals_rollout(pkg):
+    """step_slab(STEP_RANDOM) plays the same games as rollout_random / step_random (same engine RNG)."""
+    a = pkg.BatchedEnv(1500, seed=21, device=_dev())
+    b = pkg.BatchedEnv(1500, seed=21, device=_dev())
+    a.reset(); b.reset()
+    for _ in range(90):
+        a.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
+    b.rollout_random(90)
+    assert torch.equal(a.state_export(), b.state_export())
+    sa, sb = a.stats(), b.stats()
+    assert sa["plies"] == sb["plies"] and sa["episodes"] == sb["episodes"] and sa["lord_wins"] == sb["lord_wins"]
+    assert sa["legal_rows"] >= sb["legal_rows"]   # + the lists of the first legal_slab()

@@ -68,3 +68,25 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
         print(f"T={T:6d} observe={observe} hipGraph: {dt / (2 * n) * 1e6:8.1f} us/iter  {T * 2 * n / dt / 1e6:8.1f} M steps/s  "
               f"status={env.status()} plies={st['plies']}", flush=True)
     del env
+
+# slab API: one launch per iteration (step_slab applies the choices and writes the next lists)
+for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["4096", "65536"])]:
+    env = pkg.BatchedEnv(T, seed=0)
+    env.reset()
+    env.legal_slab()
+    choice = torch.zeros(T, dtype=torch.int32, device="cuda")
+    face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device="cuda")
+    for observe in (False, True):
+        for _ in range(20):
+            env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 200
+        for _ in range(n):
+            if observe:
+                env.observe(3, out=face)
+            env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"T={T:6d} observe={observe} slab API: {dt / n * 1e6:8.1f} us/iter  {T * n / dt / 1e6:8.1f} M steps/s  status={env.status()}", flush=True)
+    del env
