@@ -413,11 +413,33 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
 }
 
 
+// follows of a single, a pair or a triple (two thirds of all plies): the list is pass + the higher groups of
+// the led size + bombs + rocket (card.py:307-325).  One round, one lane per candidate, records built
+// arithmetically: no table, no planner.  lanes: 0 pass | 1..15 group of rank lane-1 | 16..28 bomb | 29 rocket
+template <int EM, bool IDS>
+__device__ __forceinline__ int simple_follow(uint64_t hand, const Follow& f, int lane, const Out& o, Pick& pk) {
+  const int cntr = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
+  const uint32_t mlc = (uint32_t)__ballot(cntr >= f.lc) & (f.lc == SINGLE ? M15 : M13);
+  const uint32_t mq = (uint32_t)__ballot(cntr >= 4) & M13;
+  const bool rocket = ((uint32_t)__ballot(cntr >= 1) & JOKERS) == JOKERS;
+  const uint32_t okm = 1u | ((mlc & gt_mask(f.lv)) << 1) | (mq << 16) | (rocket ? 1u << 29 : 0u);
+  const int r = (lane < 16 ? lane - 1 : lane - 16) & 15;
+  const bool grp = lane >= 1 && lane < 16, bomb = lane >= 16 && lane < 29;
+  const int cat = lane == 0 ? EMPTY : grp ? f.lc : bomb ? QUADRIC : BIGBANG;
+  const uint64_t nib = lane == 0 ? 0ull : lane == 29 ? ((1ull << 52) | (1ull << 56)) : (uint64_t)(grp ? f.lc : 4) << (4 * r);
+  const int id = lane == 0 ? 0 : grp ? (f.lc == SINGLE ? 1 : f.lc == DOUBLE ? 16 : 29) + r : bomb ? 42 + r : ID_BIGBANG;
+  const int vl = (lane == 0 ? 0 : lane == 29 ? 100 : r) | 0x100;
+  const bool ok = lane < 30 && ((okm >> (lane & 31)) & 1u);
+  const uint4 row = (EM == EM_WRITE || EM == EM_PICK) ? unpack_row(nib, (uint32_t)cat) : make_uint4(0, 0, 0, 0);
+  return scan_emit<EM, IDS>(ok, id, nib, cat, vl, row, o, 0, pk);
+}
+
 // lead and follow are separate instantiations: on lead every gate is true at compile time
 template <int EM, bool IDS, class HT>
 __device__ __forceinline__ int plan_scan(uint64_t hand, uint32_t info, const HT& hot, int lane, const Out& o, Pick& pk) {
   if (hand == 0 || (info & (QF_FROZEN | QF_BADLAST))) return 0;  // utils.py:48-49
   const Follow f = follow_of(info);
+  if (!f.lead && f.lc <= TRIPLE) return simple_follow<EM, IDS>(hand, f, lane, o, pk);
   return f.lead ? plan_scan_t<EM, IDS, true>(hand, f, hot, lane, o, pk) : plan_scan_t<EM, IDS, false>(hand, f, hot, lane, o, pk);
 }
 
