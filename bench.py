@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--exchange-steps", type=int, default=500, help="N > 1: iterations of the trajectory-gather leg")
+    ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the trajectory-gather leg")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE GPU (all ranks on cuda:0, gloo, host-staged gather): control-flow rehearsal only")
     a = ap.parse_args()
@@ -77,7 +78,8 @@ def main():
         if a.rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
 
     T = a.tables
     total_tables = T * world
@@ -113,40 +115,44 @@ def main():
     # writes its 32-byte trajectory record and the batch goes to the learner (rank 0) over RCCL in two
     # half-batches; the gather of the first half overlaps the rollout of the second one.
     exchange = None
-    if world > 1:
-        KX = max(2, min(K, a.exchange_steps))
-        half = KX // 2
-        shard = [T] * world
-        stage = (lambda x: x.cpu()) if a.rehearse else (lambda x: x)
-        traj_a = torch.zeros((half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
-        traj_b = torch.zeros((KX - half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
-        ddist.gather_trajectories(stage(traj_a[:1].contiguous()), dst=0, shard_sizes=shard)  # warm the collective
-        barrier()
-        tx = time.perf_counter()
-        env.rollout_random(half, traj=traj_a)
-        if a.rehearse:
-            torch.cuda.synchronize(dev)
-        pending = ddist.gather_trajectories(stage(traj_a), dst=0, async_op=True, shard_sizes=shard)
-        env.rollout_random(KX - half, traj=traj_b)
-        if a.rehearse:
-            torch.cuda.synchronize(dev)
-        tail = ddist.gather_trajectories(stage(traj_b), dst=0, async_op=True, shard_sizes=shard)
-        ga, gb = pending.result(), tail.result()
-        barrier()
-        dtx = time.perf_counter() - tx
-        tmx = torch.tensor([dtx], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
-        dtx = float(tmx.item())
-        if rank == 0:
-            assert ga.shape == (half, total_tables, pkg.TRAJ_BYTES) and gb.shape == (KX - half, total_tables, pkg.TRAJ_BYTES)
-            rec = ddist.unpack_trajectory(gb[-1].to(dev))
-            assert int(rec["ply"].max()) < 400 and int(rec["role"].max()) <= 2
-        exchange = {"steps": KX, "env_steps_per_s_with_gather": total_tables * KX / dtx,
-                    "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_BYTES, "seconds": dtx,
-                    "note": "trajectory records (32 B per ply per table) written and gathered to rank 0, pipelined "
-                            "in two half-batches; measured after the headline region"}
-        del traj_a, traj_b, ga, gb
-        s1 = env.stats()
+    if world > 1 and not a.no_exchange:
+        try:
+            KX = max(2, min(K, a.exchange_steps))
+            half = KX // 2
+            shard = [T] * world
+            stage = (lambda x: x.cpu()) if a.rehearse else (lambda x: x)
+            traj_a = torch.zeros((half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
+            traj_b = torch.zeros((KX - half, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
+            ddist.gather_trajectories(stage(traj_a[:1].contiguous()), dst=0, shard_sizes=shard)  # warm the collective
+            barrier()
+            tx = time.perf_counter()
+            env.rollout_random(half, traj=traj_a)
+            if a.rehearse:
+                torch.cuda.synchronize(dev)
+            pending = ddist.gather_trajectories(stage(traj_a), dst=0, async_op=True, shard_sizes=shard)
+            env.rollout_random(KX - half, traj=traj_b)
+            if a.rehearse:
+                torch.cuda.synchronize(dev)
+            tail = ddist.gather_trajectories(stage(traj_b), dst=0, async_op=True, shard_sizes=shard)
+            ga, gb = pending.result(), tail.result()
+            barrier()
+            dtx = time.perf_counter() - tx
+            tmx = torch.tensor([dtx], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            dtx = float(tmx.item())
+            if rank == 0:
+                assert ga.shape == (half, total_tables, pkg.TRAJ_BYTES) and gb.shape == (KX - half, total_tables, pkg.TRAJ_BYTES)
+                rec = ddist.unpack_trajectory(gb[-1].to(dev))
+                assert int(rec["ply"].max()) < 400 and int(rec["role"].max()) <= 2
+            exchange = {"steps": KX, "env_steps_per_s_with_gather": total_tables * KX / dtx,
+                        "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_BYTES, "seconds": dtx,
+                        "note": "trajectory records (32 B per ply per table) written and gathered to rank 0, pipelined "
+                                "in two half-batches; measured after the headline region"}
+            del traj_a, traj_b, ga, gb
+            s1 = env.stats()
+        except Exception as ex:  # the headline above stands on its own; report, do not lose the line
+            exchange = {"error": repr(ex)[:300]}
+            s1 = env.stats()
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
     # duration of the dominant kernel: all iterations run inside ONE k_rollout launch; two HIP
