@@ -584,8 +584,13 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     const bool active = dealt && !is_done;
     const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
     uint64_t hand = rl64(P, DDZ_F_HAND0 + role);
-    uint32_t info = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
-                              rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+    const uint64_t n1 = rl64(P, DDZ_F_RECENT0 + rm1);  // what the previous player played (0 = pass)
+    const int cat1 = (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24);
+    uint32_t info = last_info(n1, cat1, rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+    // the query of the NEXT actor follows from this decode (no second decode of the updated rows): its hand is
+    // untouched by this ply, and it has to beat this ply's combo, or -- after a pass -- the previous player's
+    uint64_t qhand = (COUNT || SLAB) ? rl64(P, DDZ_F_HAND0 + rp1) : 0;
+    uint32_t qinfo = mk_info(EMPTY, 0, 1);
     int cnt = 0;
     Pick pk{-1, 0, 0, 0, 0};
     if (ENUM) {
@@ -662,7 +667,9 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       } else {
         changed = true;
         const uint32_t cw3 = c3 & 0x00FFFFFFu;
-        const uint32_t ncards = (uint32_t)nib_sum(pack_row(make_uint4(c0, c1, c2, c3)));
+        const uint64_t cn = pack_row(make_uint4(c0, c1, c2, c3));
+        const uint32_t ncards = (uint32_t)nib_sum(cn);
+        qinfo = cn ? info_of_row(cn, (int)(c3 >> 24)) : (n1 ? info_of_row(n1, cat1) : mk_info(EMPTY, 0, 1));
         // lane-parallel update of the table's rows (envi.py:39-43); byte-wise: every byte
         // of the hand >= the row's byte, so no borrow/carry crosses a byte
         if (lane == DDZ_F_HAND0 + role) {
@@ -688,6 +695,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
           R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
               : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
           role = 1; is_done = false;
+          qhand = h1; qinfo = mk_info(EMPTY, 0, 1);  // the lord leads
         } else {
           if (lane == DDZ_F_META)
             R = make_uint4((uint32_t)nrole | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) | (o_reward << 24),
@@ -712,16 +720,14 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
             : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
         role = 1; is_done = false; dealt = true;
+        qhand = h1; qinfo = mk_info(EMPTY, 0, 1);
       }
     }
     if (changed) {
       if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
       if (COUNT || SLAB) {                     // query of the new actor
-        P = pack_row(R);
-        const int q1 = role == 0 ? 2 : role - 1, q2 = role == 2 ? 0 : role + 1;
-        hand = rl64(P, DDZ_F_HAND0 + role);
-        info = last_info(rl64(P, DDZ_F_RECENT0 + q1), (int)(rl(R.w, DDZ_F_RECENT0 + q1) >> 24),
-                         rl64(P, DDZ_F_RECENT0 + q2), (int)(rl(R.w, DDZ_F_RECENT0 + q2) >> 24));
+        hand = qhand;
+        info = qinfo;
       }
     }
     if (COUNT) {
