@@ -1599,14 +1599,19 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
   RolloutArgs a;
   a.state = e->state; a.T = e->T; a.tpw = e->tpw;
   a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
-  a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride; a.n_iters = n_iters;
-  a.traj = (uint4*)traj;
+  a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-  if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true>), grid, block, 0, st, a);
-  else if (ids) hipLaunchKernelGGL((k_rollout<true, false>), grid, block, 0, st, a);
-  else if (traj) hipLaunchKernelGGL((k_rollout<false, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_rollout<false, false>), grid, block, 0, st, a);
+  // the kernel counts iterations and plies in 32 bits: at most 2^20 iterations per launch (about a second)
+  constexpr int64_t CHUNK = 1 << 20;
+  for (int64_t done = 0; done < n_iters; done += CHUNK) {
+    a.n_iters = n_iters - done < CHUNK ? n_iters - done : CHUNK;
+    a.traj = traj ? (uint4*)(traj + done * e->T * DDZ_TRAJ_BYTES) : nullptr;
+    if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true>), grid, block, 0, st, a);
+    else if (ids) hipLaunchKernelGGL((k_rollout<true, false>), grid, block, 0, st, a);
+    else if (traj) hipLaunchKernelGGL((k_rollout<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_rollout<false, false>), grid, block, 0, st, a);
+  }
   e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
   return check_launch();
 }
