@@ -41,7 +41,16 @@ def cpu_baseline(tables, budget_s):
     t0 = time.perf_counter()
     pliesm, _, _ = oracle.rollout_random_mt(env, nm, cores)
     dtm = time.perf_counter() - t0
-    return {"value": pliesm / dtm, "unit": "env steps/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": pliesm / dtm, "unit": "env steps/s", "cores": cores, "kind": "port", "cpu_model": model,
             "single_core_value": plies1 / dt1,
             "sample": f"{nm} lock-step iterations x {tables} tables over {cores} threads in {dtm:.1f} s "
                       f"(and {n1} iterations on 1 thread in {dt1:.1f} s); oracle/ddz_oracle.c, dense "
