@@ -100,12 +100,14 @@ struct Out {
   uint64_t* stage;      // EM_STAGE: per-wave LDS list of nib | category << 60, in id order,
   uint16_t* stage_vl;   //           value | len << 8 of each entry (card.py:327-335)
   uint16_t* stage_ids;  //           and (IDS) the canonical ids
+  uint32_t* mask;       // EM_MASK: per-wave LDS bit mask over the action space (bit id)
 };
 // what a scan does with the legal lanes
 constexpr int EM_COUNT = 0;   // nothing (list size only)
 constexpr int EM_WRITE = 1;   // rows (+ids) into the CSR list at base + running index
 constexpr int EM_PICK = 2;    // EM_WRITE + capture the row with list index pk.want
 constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS staging list
+constexpr int EM_MASK = 4;    // bit `id` of the wave's LDS mask (get_mask, utils.py:45-63)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
 constexpr int STAGE_CAP = DDZ_NATIVE_JOKER_KICKERS ? 512 : 500;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py);
@@ -222,7 +224,9 @@ __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int c
                                          int n, Pick& pk) {
   const uint64_t b = __ballot(legal);
   const int k = __popcll(b);
-  if (EM != EM_COUNT) {
+  if (EM == EM_MASK) {
+    if (legal) atomicOr(&o.mask[id >> 5], 1u << (id & 31));
+  } else if (EM != EM_COUNT) {
     const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
     if (EM == EM_STAGE) {
       if (legal && n + pre < STAGE_CAP) {
@@ -1056,6 +1060,51 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_mask: the legal moves of every table as a dense 0/1 mask over the action space -- the form the reference's
+// rules produce (get_mask, rule_based/utils/utils.py:45-63; mask[0] = pass) and what a policy head with one logit
+// per action consumes.  Bit-packed: MASK_WORDS u32 per table, bit (id & 31) of word id >> 5.  One wavefront per
+// table: bits are set in an LDS mask during the scan, then streamed out (write-once: nontemporal stores).
+constexpr int MASK_WORDS = (DDZ_NUM_ACTIONS + 24 + 31) / 32;  // 424: also covers the joker-kicker build
+
+__global__ __launch_bounds__(TB, 4) void k_mask(const uint8_t* __restrict__ state, int64_t T, int tpw,
+                                                uint32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
+  const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
+  __shared__ HotTabT<false> hot;
+  __shared__ uint32_t s_mask[WPB][MASK_WORDS];
+  uint4 Rnext = make_uint4(0, 0, 0, 0);
+  if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(state + t0 * STATE_ROW_BYTES))[lane];
+  hot_fill<TB>(hot);
+  __syncthreads();
+  uint32_t* mask = s_mask[wv];
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    const uint4 R = Rnext;
+    if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(state + (t + 1) * STATE_ROW_BYTES))[lane];
+    for (int w = lane; w < MASK_WORDS; w += 64) mask[w] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t P = pack_row(R);
+    const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META);
+    int role = mx & 0xFF;
+    if (role > 2) role = 0;
+    const bool active = ((my >> 16) & 0xFF) && !((mx >> 8) & 0xFF);  // dealt and not done
+    const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+    const uint64_t hand = rl64(P, DDZ_F_HAND0 + role);
+    const uint32_t info = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
+                                    rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+    const Out o{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, mask};
+    Pick pk{-1, 0, 0, 0, 0};
+    plan_scan<EM_MASK, false>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* dst = out + t * MASK_WORDS;
+    for (int w = lane; w < MASK_WORDS; w += 64) __builtin_nontemporal_store(mask[w], dst + w);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // stateless path: r.get_moves(hand15, last15) for n independent (hand, last) pairs, one
 // wavefront per query (tpw consecutive queries per wave); pass 1 (WRITE = false) sizes the
 // lists and scans them per block, pass 2 writes the CSR list.
@@ -1541,6 +1590,18 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
     case DDZ_STEP_CHOICE: return launch_table<F_STEP | F_SLAB, DDZ_STEP_CHOICE>(e, io, st);
     default: return launch_table<F_STEP | F_SLAB, DDZ_STEP_ROWS>(e, io, st);
   }
+}
+
+int ddz_mask_words(void) { return MASK_WORDS; }
+
+int ddz_legal_mask(ddz_env_t* e, uint32_t* mask, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!mask) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_mask, dim3((unsigned)e->nblocks), dim3(TB), 0, (hipStream_t)stream, (const uint8_t*)e->state,
+                     e->T, e->tpw, mask);
+  return check_launch();
 }
 
 int ddz_observe(ddz_env_t* e, int variant, float* face, void* stream) {

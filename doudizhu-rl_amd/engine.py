@@ -204,6 +204,21 @@ class BatchedEnv:
         st = self.slab_stride
         return None if self.ids is None else self.ids[: self.T * st].view(self.T, st)
 
+    def legal_mask(self, out=None, unpack=False):
+        """get_mask (rule_based/utils/utils.py:45-63) of every table: the legal moves as a dense mask over the
+        action space.  Bit-packed int32 [T, 424] (bit id & 31 of word id >> 5; bit 0 = pass), or with
+        unpack=True a bool [T, n_actions] tensor (a policy head with one logit per action masks with it)."""
+        W = self.lib.ddz_mask_words()
+        if out is None:
+            out = torch.empty((self.T, W), dtype=torch.int32, device=self.device)
+        elif out.dtype != torch.int32 or tuple(out.shape) != (self.T, W) or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous int32 [T,{W}] tensor")
+        check(self.lib.ddz_legal_mask(self._h, _p(out), _stream(self.device)))
+        if not unpack:
+            return out
+        bits = (out.unsqueeze(-1) >> torch.arange(32, device=self.device, dtype=torch.int32)) & 1
+        return bits.view(self.T, W * 32)[:, : self.lib.ddz_num_actions()].bool()
+
     def legal_slab(self):
         """Legal-move lists of all tables in the slab layout: (counts[T] i32, rows [T,stride,16] i8,
         ids [T,stride] i32 | None); table t's moves are rows[t, :counts[t]] in ascending canonical id.

@@ -109,6 +109,12 @@ int ddz_step(ddz_env_t* env, int mode, const void* sel, const int32_t* offsets,
              const int8_t* rows, int auto_reset, uint8_t* done, int8_t* reward,
              uint8_t* illegal, uint8_t* traj, void* stream);
 
+/* get_mask (rule_based/utils/utils.py:45-63) for every table: the legal moves as a dense 0/1 mask over the
+ * action space (bit id; bit 0 = pass, forced 0 on lead), bit-packed into ddz_mask_words() = 424 uint32 per table
+ * (bit id & 31 of word id >> 5; the tail bits are 0).  mask: [T][424] uint32, device memory.                  */
+int ddz_mask_words(void);
+int ddz_legal_mask(ddz_env_t* env, uint32_t* mask, void* stream);
+
 /* Slab variant of ddz_legal / ddz_step (fixed-stride list layout, as ddz_rollout_random uses): table t owns
  * rows[t * stride ... t * stride + counts[t]).  Without the CSR prefix there is no dependency between tables,
  * so ONE launch per lock-step iteration does both halves of the reference's loop body (game.py:95-106 +

@@ -662,3 +662,31 @@ def test_slab_api_random_equals_rollout(pkg):
     sa, sb = a.stats(), b.stats()
     assert sa["plies"] == sb["plies"] and sa["episodes"] == sb["episodes"] and sa["lord_wins"] == sb["lord_wins"]
     assert sa["legal_rows"] >= sb["legal_rows"]   # + the lists of the first legal_slab()
+
+
+@pytest.mark.parametrize("jk", [False, True])
+def test_legal_mask_vs_oracle(pkg, oracle, jk):
+    """ddz_legal_mask = the reference's get_mask for every table: bit id set <=> id in the oracle's legal list
+    (lead, follow, frozen tables), bit-packed and unpacked forms, default and joker-kicker rule sets."""
+    T = 900
+    with oracle.variant(jk=jk):
+        env = pkg.BatchedEnv(T, seed=31, device=_dev(), native_joker_kickers=jk)
+        ref = oracle.OracleEnv(T, seed=31)
+        env.reset(); ref.reset()
+        na = oracle.num_actions()
+        for it in range(60):
+            if it % 6 == 0:
+                roff, _, rids = ref.legal()
+                want = np.zeros((T, na), bool)
+                want[np.repeat(np.arange(T), np.diff(roff)), rids] = True
+                got = env.legal_mask(unpack=True).cpu().numpy()
+                assert got.shape == (T, na) and np.array_equal(got, want)
+                packed = env.legal_mask().cpu().numpy().view(np.uint32)
+                assert packed.shape == (T, 424)
+                assert np.array_equal(np.unpackbits(packed.view(np.uint8), axis=1, bitorder="little")[:, :na].astype(bool), want)
+                assert not np.unpackbits(packed.view(np.uint8), axis=1, bitorder="little")[:, na:].any()
+            auto = it < 40   # later: finished tables stay frozen -> all-zero mask rows
+            env.step(None, pkg.STEP_RANDOM, auto_reset=auto)
+            ref.legal(); ref.step(oracle.STEP_RANDOM, auto_reset=auto)
+        frozen = env.field(10)[:, 1].cpu().numpy() != 0
+        assert frozen.any() and not env.legal_mask(unpack=True).cpu().numpy()[frozen].any()
