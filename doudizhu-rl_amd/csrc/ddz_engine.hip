@@ -1073,17 +1073,19 @@ __global__ __launch_bounds__(TB, 4) void k_mask(const uint8_t* __restrict__ stat
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
   const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
   __shared__ HotTabT<false> hot;
-  __shared__ uint32_t s_mask[WPB][MASK_WORDS];
+  static_assert(MASK_WORDS % 4 == 0, "the mask is moved in 16-byte pieces");
+  __shared__ uint4 s_mask[WPB][MASK_WORDS / 4];
   uint4 Rnext = make_uint4(0, 0, 0, 0);
   if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(state + t0 * STATE_ROW_BYTES))[lane];
   hot_fill<TB>(hot);
   __syncthreads();
-  uint32_t* mask = s_mask[wv];
+  uint4* mask4 = s_mask[wv];
+  uint32_t* mask = (uint32_t*)mask4;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     const uint4 R = Rnext;
     if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(state + (t + 1) * STATE_ROW_BYTES))[lane];
-    for (int w = lane; w < MASK_WORDS; w += 64) mask[w] = 0;
+    for (int w = lane; w < MASK_WORDS / 4; w += 64) mask4[w] = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     const uint64_t P = pack_row(R);
     const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META);
@@ -1098,8 +1100,12 @@ __global__ __launch_bounds__(TB, 4) void k_mask(const uint8_t* __restrict__ stat
     Pick pk{-1, 0, 0, 0, 0};
     plan_scan<EM_MASK, false>(hand, active ? info : QF_FROZEN, hot, lane, o, pk);
     __builtin_amdgcn_wave_barrier();
-    uint32_t* dst = out + t * MASK_WORDS;
-    for (int w = lane; w < MASK_WORDS; w += 64) __builtin_nontemporal_store(mask[w], dst + w);
+    uint4* dst = (uint4*)(out + t * MASK_WORDS);  // 1696 B per table: 16-byte aligned
+    for (int w = lane; w < MASK_WORDS / 4; w += 64) {
+      const uint4 v = mask4[w];
+      __builtin_nontemporal_store(v.x, &dst[w].x); __builtin_nontemporal_store(v.y, &dst[w].y);
+      __builtin_nontemporal_store(v.z, &dst[w].z); __builtin_nontemporal_store(v.w, &dst[w].w);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
