@@ -1188,10 +1188,14 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
 __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ state, int64_t T, uint32_t k0, uint32_t k1,
                                                   uint64_t gid_base, const float* __restrict__ q,
                                                   const int32_t* __restrict__ offsets, uint64_t thr,
-                                                  int32_t* __restrict__ choice) {
+                                                  int32_t* __restrict__ choice, const int32_t* __restrict__ counts,
+                                                  int64_t stride) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (t >= T) return;
-  const int32_t off = offsets[t], A = offsets[t + 1] - off;
+  // CSR: segment [offsets[t], offsets[t+1]); slab (counts != null): [t * stride, t * stride + counts[t])
+  const int64_t off = counts ? t * stride : (int64_t)offsets[t];
+  int32_t A = counts ? counts[t] : offsets[t + 1] - offsets[t];
+  if (counts && A > stride) A = 0;
   if (A <= 0) {
     choice[t] = -1;
     return;
@@ -1774,7 +1778,20 @@ int ddz_select(ddz_env_t* e, const float* q, const int32_t* offsets, double epsi
   const uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
   hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q, offsets,
-                     thr, choice);
+                     thr, choice, (const int32_t*)nullptr, (int64_t)0);
+  return check_launch();
+}
+
+int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t stride, double epsilon, int32_t* choice,
+                    void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!q || !counts || stride <= 0 || !choice || !(epsilon >= 0.0) || epsilon > 1.0) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  const uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q,
+                     (const int32_t*)nullptr, thr, choice, counts, stride);
   return check_launch();
 }
 

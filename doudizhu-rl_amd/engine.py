@@ -182,6 +182,20 @@ class BatchedEnv:
                                   _stream(self.device)))
         return out
 
+    def select_slab(self, q, epsilon=0.0, out=None):
+        """select() for the slab layout: q f32 [T, stride] (entries beyond counts[t] are ignored); returns
+        int32[T] indices for step_slab(STEP_CHOICE).  Same greedy / epsilon-greedy rule and RNG as select()."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        if q.numel() != self.T * self.slab_stride:
+            raise ValueError("q must be [T, stride]")
+        if out is None:
+            out = torch.empty(self.T, dtype=torch.int32, device=self.device)
+        check(self.lib.ddz_select_slab(self._h, _p(q), _p(self.counts), self.slab_stride, float(epsilon), _p(out),
+                                       _stream(self.device)))
+        return out
+
     def legal_onehot(self):
         """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
         self._need_legal()

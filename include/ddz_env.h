@@ -185,6 +185,10 @@ int ddz_read_stats(ddz_env_t* env, int64_t* stats, void* stream);
 int ddz_select(ddz_env_t* env, const float* q, const int32_t* offsets, double epsilon,
                int32_t* choice, void* stream);
 
+/* ddz_select for the slab layout: q is f32 [T][stride] (values beyond counts[t] are ignored). */
+int ddz_select_slab(ddz_env_t* env, const float* q, const int32_t* counts, int64_t stride, double epsilon,
+                    int32_t* choice, void* stream);
+
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */
 int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);

@@ -690,3 +690,32 @@ def test_legal_mask_vs_oracle(pkg, oracle, jk):
             ref.legal(); ref.step(oracle.STEP_RANDOM, auto_reset=auto)
         frozen = env.field(10)[:, 1].cpu().numpy() != 0
         assert frozen.any() and not env.legal_mask(unpack=True).cpu().numpy()[frozen].any()
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.3])
+def test_select_slab_equals_select(pkg, eps):
+    """The slab form of ddz_select picks exactly what the CSR form picks for the same per-move values
+    (same arg-max rule, same exploration RNG), and step_slab(choice) == step(choice)."""
+    T = 3000
+    a = pkg.BatchedEnv(T, seed=5, device=_dev())
+    b = pkg.BatchedEnv(T, seed=5, device=_dev())
+    a.reset(); b.reset()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for it in range(40):
+        off, rows, _ = a.legal()
+        counts, srows, _ = b.legal_slab()
+        n = off.diff().long()
+        assert torch.equal(n.to(torch.int32), counts)
+        total = int(off[-1])
+        q = torch.rand(total, generator=g).to(_dev())
+        q[torch.rand(total, generator=g).to(_dev()) < 0.2] = 0.5        # ties: first maximum wins
+        seg = torch.repeat_interleave(torch.arange(T, device=_dev()), n, output_size=total)
+        pos = torch.arange(total, device=_dev()) - off[:-1].long()[seg]
+        qs = torch.full((T, b.slab_stride), 9.0, device=_dev())         # garbage beyond counts must be ignored
+        qs[seg, pos] = q
+        ca, cb = a.select(q, eps), b.select_slab(qs, eps)
+        assert torch.equal(ca, cb)
+        da = a.step(ca, pkg.STEP_CHOICE, auto_reset=True)
+        db = b.step_slab(cb, pkg.STEP_CHOICE, auto_reset=True)
+        assert all(torch.equal(x, y) for x, y in zip(da, db))
+    assert torch.equal(a.state_export(), b.state_export())
