@@ -719,3 +719,25 @@ def test_select_slab_equals_select(pkg, eps):
         db = b.step_slab(cb, pkg.STEP_CHOICE, auto_reset=True)
         assert all(torch.equal(x, y) for x, y in zip(da, db))
     assert torch.equal(a.state_export(), b.state_export())
+
+
+def test_get_moves_random_sweep(pkg, oracle, golden):
+    """4000 random (hand, last) pairs: hands of 1..20 random cards, `last` a uniformly random action of the
+    whole action space (every category, every length, including ones the hand cannot answer) or a lead."""
+    rng = np.random.default_rng(2024)
+    table = golden("action_table.npz")
+    deck = np.repeat(np.arange(15), [4] * 13 + [1, 1])
+    n = 4000
+    hands = np.zeros((n, 15), np.int8)
+    lasts = np.zeros((n, 15), np.int8)
+    for i in range(n):
+        k = int(rng.integers(1, 21))
+        hands[i] = np.bincount(rng.choice(deck, k, replace=False), minlength=15)
+        if i % 5:
+            lasts[i] = table["rows"][rng.integers(1, NA)]
+    offsets, rows, ids = pkg.get_moves(torch.from_numpy(hands).to(_dev()), torch.from_numpy(lasts).to(_dev()))
+    offsets, ids = offsets.cpu().numpy(), ids.cpu().numpy()
+    for i in range(n):
+        want = oracle.legal(hands[i], lasts[i] if lasts[i].any() else None)
+        assert np.array_equal(ids[offsets[i]:offsets[i + 1]], want), (i, hands[i], lasts[i])
+    assert np.array_equal(rows.cpu().numpy()[:, :15], table["rows"][ids])
