@@ -45,6 +45,8 @@ SYMBOLS = {
     "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "ddz_select_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "ddz_action_table": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "ddz_pack_trajectory": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

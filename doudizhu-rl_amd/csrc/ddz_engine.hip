@@ -1320,6 +1320,48 @@ __global__ __launch_bounds__(BLOCK) void k_onehot(const uint8_t* __restrict__ ro
 }
 
 // ------------------------------------------------------------------------------------
+// action table export and the compact trajectory record.
+constexpr int NUM_ACTIONS_X = DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS;
+__device__ uint64_t g_sorted_nib[NUM_ACTIONS_X];  // packed rows of all actions, ascending (host-sorted once)
+__device__ int32_t g_sorted_id[NUM_ACTIONS_X];    // ... and their canonical ids
+
+// rows[id] = int8 counts[15] + category of action id (card.py:34-159 order; + the joker-kicker rows)
+__global__ __launch_bounds__(BLOCK) void k_export_table(uint4* __restrict__ rows) {
+  const int id = (int)(blockIdx.x * BLOCK + threadIdx.x);
+  if (id >= NUM_ACTIONS_X) return;
+  if (id < DDZ_NUM_ACTIONS) {
+    rows[id] = g_tab[2 * id];
+    return;
+  }
+  const int k = id - DDZ_NUM_ACTIONS;  // 0..12 quad + jokers, 13..23 two triples + jokers
+  const uint64_t jk = (1ull << 52) | (1ull << 56);
+  rows[id] = k < 13 ? unpack_row((4ull << (4 * k)) | jk, FOUR_TAKE_ONE)
+                    : unpack_row((0x33ull << (4 * (k - 13))) | jk, THREE_ONE_LINE);
+}
+
+// 32-byte trajectory record -> 8 bytes (what has to cross xGMI): the action as its canonical id
+//   w0: id (14 bits) | n_legal << 14 (9) | role << 23 (2) | done << 25 | reward code << 26 (0: 0, 1: +1, 2: -1) | flags << 28 (2)
+//   w1: choice + 1 (10 bits) | ply << 10 (8) | episode << 18 (low 14 bits)
+__global__ __launch_bounds__(BLOCK) void k_pack_traj(const uint4* __restrict__ traj, int64_t n, uint2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint4 row = traj[2 * i], m = traj[2 * i + 1];
+  const uint64_t nib = pack_row(row);
+  int lo = 0, hi = NUM_ACTIONS_X - 1, id = 0x3FFF;  // 0x3FFF: not a row of the action space
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const uint64_t v = g_sorted_nib[mid];
+    if (v == nib) { id = g_sorted_id[mid]; break; }
+    if (v < nib) lo = mid + 1; else hi = mid - 1;
+  }
+  const uint32_t role = m.x & 0xFF, done = (m.x >> 8) & 1, rew = (m.x >> 16) & 0xFF, flags = (m.x >> 24) & 3;
+  const uint32_t rc = rew == 0 ? 0u : rew == 1 ? 1u : 2u;
+  const uint32_t w0 = (uint32_t)id | ((m.y & 0x1FF) << 14) | ((role & 3) << 23) | (done << 25) | (rc << 26) | (flags << 28);
+  const uint32_t w1 = (((uint32_t)((int32_t)m.w + 1)) & 0x3FF) | (((m.y >> 16) & 0xFF) << 10) | ((m.z & 0x3FFF) << 18);
+  out[i] = make_uint2(w0, w1);
+}
+
+// ------------------------------------------------------------------------------------
 // host side
 thread_local int g_last_hip = 0;
 constexpr uint32_t MAGIC = 0xDD2E0001u;
@@ -1394,6 +1436,33 @@ int ensure_table(int device) {
   if (rc == DDZ_OK && r != hipSuccess) rc = hip_fail(r);
   if (rc == DDZ_OK && *flag != 0) rc = DDZ_EHIP;
   (void)hipHostFree(flag);
+  if (rc == DDZ_OK) {  // nib -> id lookup for the compact trajectory record: sorted once on the host
+    struct Rec { uint64_t nib; int32_t id; };
+    Rec* recs = (Rec*)malloc(sizeof(Rec) * NUM_ACTIONS_X);
+    uint4* tab = (uint4*)malloc(sizeof(uint4) * 2 * DDZ_NUM_ACTIONS);
+    uint64_t* nibs = (uint64_t*)malloc(sizeof(uint64_t) * NUM_ACTIONS_X);
+    int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * NUM_ACTIONS_X);
+    if (!recs || !tab || !nibs || !ids) rc = DDZ_EINVAL;
+    if (rc == DDZ_OK) {
+      r = hipMemcpyFromSymbol(tab, HIP_SYMBOL(g_tab), sizeof(uint4) * 2 * DDZ_NUM_ACTIONS);
+      if (r != hipSuccess) rc = hip_fail(r);
+    }
+    if (rc == DDZ_OK) {
+      for (int i = 0; i < DDZ_NUM_ACTIONS; ++i) recs[i] = Rec{(uint64_t)tab[2 * i + 1].x | ((uint64_t)tab[2 * i + 1].y << 32), i};
+      const uint64_t jk = (1ull << 52) | (1ull << 56);
+      for (int k = 0; k < NUM_ACTIONS_X - DDZ_NUM_ACTIONS; ++k)
+        recs[DDZ_NUM_ACTIONS + k] = Rec{(k < 13 ? (4ull << (4 * k)) : (0x33ull << (4 * (k - 13)))) | jk, DDZ_NUM_ACTIONS + k};
+      qsort(recs, NUM_ACTIONS_X, sizeof(Rec), [](const void* a, const void* b) {
+        const uint64_t x = ((const Rec*)a)->nib, y = ((const Rec*)b)->nib;
+        return x < y ? -1 : x > y ? 1 : 0;
+      });
+      for (int i = 0; i < NUM_ACTIONS_X; ++i) { nibs[i] = recs[i].nib; ids[i] = recs[i].id; }
+      r = hipMemcpyToSymbol(HIP_SYMBOL(g_sorted_nib), nibs, sizeof(uint64_t) * NUM_ACTIONS_X);
+      if (r == hipSuccess) r = hipMemcpyToSymbol(HIP_SYMBOL(g_sorted_id), ids, sizeof(int32_t) * NUM_ACTIONS_X);
+      if (r != hipSuccess) rc = hip_fail(r);
+    }
+    free(recs); free(tab); free(nibs); free(ids);
+  }
   if (rc == DDZ_OK) g_table_ready[device] = true;
   return rc;
 }
@@ -1792,6 +1861,29 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
   hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q,
                      (const int32_t*)nullptr, thr, choice, counts, stride);
+  return check_launch();
+}
+
+int ddz_action_table(int device, int8_t* rows, void* stream) {
+  if (!rows) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_export_table, dim3((NUM_ACTIONS_X + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (uint4*)rows);
+  return check_launch();
+}
+
+int ddz_pack_trajectory(int device, const uint8_t* traj, int64_t n_records, uint8_t* packed, void* stream) {
+  if (n_records < 0 || (n_records > 0 && (!traj || !packed))) return DDZ_EINVAL;
+  if (n_records == 0) return DDZ_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pack_traj, dim3((unsigned)((n_records + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (const uint4*)traj, n_records, (uint2*)packed);
   return check_launch();
 }
 

@@ -39,7 +39,7 @@ class _Pending:
         return self._out
 
 
-def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=None):
+def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=None, compact=False):
     """traj: uint8 [n_iters, T_local, 32] of this rank -> uint8 [n_iters, T_total, 32], tables in
     global id order, on every rank (dst=None: all_gather) or only on rank `dst` (gather to the
     learner; the other ranks get None).  One collective per call (few, large messages: xGMI is
@@ -47,9 +47,15 @@ def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=
     handle at once -- the collective runs on the process group's own stream, so the next
     rollout on the current stream overlaps it -- and handle.result() waits for it.
     shard_sizes (tables per rank, if the caller knows them) skips the size exchange and its
-    host sync."""
-    if traj.dtype != torch.uint8 or traj.dim() != 3 or traj.shape[2] != TRAJ_BYTES:
-        raise ValueError("traj must be uint8 [n_iters, T_local, 32]")
+    host sync.  compact=True (GPU tensors): the records are packed to 8 bytes (the action as its
+    canonical id, engine.pack_trajectory) before the collective -- 4x fewer bytes over xGMI -- and the
+    result is uint8 [n_iters, T_total, 8]; unpack_trajectory() reads both forms."""
+    if traj.dtype != torch.uint8 or traj.dim() != 3 or traj.shape[2] not in (TRAJ_BYTES, 8):
+        raise ValueError("traj must be uint8 [n_iters, T_local, 32] (or already packed: [..., 8])")
+    if compact and traj.shape[2] == TRAJ_BYTES:
+        from .engine import pack_trajectory
+        traj = pack_trajectory(traj)
+    rec = traj.shape[2]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         pend = _Pending([], lambda: traj)
         return pend if async_op else pend.result()
@@ -67,10 +73,10 @@ def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=
     t_max = max(all_sizes)
     send = traj.contiguous()
     if t_local != t_max:
-        pad = torch.zeros((n_iters, t_max - t_local, TRAJ_BYTES), dtype=torch.uint8, device=traj.device)
+        pad = torch.zeros((n_iters, t_max - t_local, rec), dtype=torch.uint8, device=traj.device)
         send = torch.cat([send, pad], dim=1).contiguous()
     receives = dst is None or rank == dst
-    recv = (torch.empty((world, n_iters, t_max, TRAJ_BYTES), dtype=torch.uint8, device=traj.device)
+    recv = (torch.empty((world, n_iters, t_max, rec), dtype=torch.uint8, device=traj.device)
             if receives else None)
     if dst is None:
         work = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group, async_op=True)
@@ -88,8 +94,23 @@ def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=
     return pend if async_op else pend.result()
 
 
-def unpack_trajectory(traj):
-    """Named int views of packed records [..., 32] (layout: DESIGN.md / include/ddz_env.h)."""
+def unpack_trajectory(traj, action_rows=None):
+    """Named int views of trajectory records: [..., 32] (layout: DESIGN.md / include/ddz_env.h) or the
+    compact [..., 8] form (then "id" is the canonical action id -- 0x3FFF for a record that holds no action
+    of the table -- and "row" is filled in when `action_rows` = engine.action_table() is given; "episode"
+    holds the low 14 bits)."""
+    if traj.shape[-1] == 8:
+        t = traj.to(torch.int64)
+        w = lambda lo: t[..., lo] | (t[..., lo + 1] << 8) | (t[..., lo + 2] << 16) | (t[..., lo + 3] << 24)  # noqa: E731
+        w0, w1 = w(0), w(4)
+        rc = (w0 >> 26) & 3
+        out = {"id": w0 & 0x3FFF, "n_legal": (w0 >> 14) & 0x1FF, "role": (w0 >> 23) & 3, "done": (w0 >> 25) & 1,
+               "reward": torch.where(rc == 2, -torch.ones_like(rc), rc), "flags": (w0 >> 28) & 3,
+               "choice": (w1 & 0x3FF) - 1, "ply": (w1 >> 10) & 0xFF, "episode": (w1 >> 18) & 0x3FFF}
+        if action_rows is not None:
+            ids = out["id"].clamp(max=action_rows.shape[0] - 1).to(action_rows.device)
+            out["row"] = action_rows[ids]
+        return out
     t = traj.to(torch.int64)
     u16 = lambda lo: t[..., lo] | (t[..., lo + 1] << 8)  # noqa: E731
     u32 = lambda lo: u16(lo) | (u16(lo + 2) << 16)       # noqa: E731

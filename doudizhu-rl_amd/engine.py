@@ -344,6 +344,33 @@ def rows_to_onehot(rows):
     return out
 
 
+def action_table(device="cuda:0", native_joker_kickers=False):
+    """The canonical action table on the device: int8 [n_actions, 16] = counts[15] + category, action id =
+    row index (the order of card.py:34-159 get_action_space(); + the 24 joker-kicker rows if asked for)."""
+    L = _lib.lib(jk=native_joker_kickers)
+    dev = _require_gpu(device)
+    rows = torch.empty((L.ddz_num_actions(), ROW), dtype=torch.int8, device=dev)
+    check(L.ddz_action_table(dev.index, _p(rows), _stream(dev)))
+    return rows
+
+
+TRAJ_PACKED_BYTES = 8
+
+
+def pack_trajectory(traj, native_joker_kickers=False):
+    """uint8 [..., 32] trajectory records -> uint8 [..., 8] (include/ddz_env.h ddz_pack_trajectory): the action
+    as its canonical id.  What dist.gather_trajectories(compact=True) sends over xGMI."""
+    L = _lib.lib(jk=native_joker_kickers)
+    dev = _require_gpu(traj.device)
+    if traj.dtype != torch.uint8 or traj.shape[-1] != TRAJ_BYTES:
+        raise ValueError("traj must be uint8 [..., 32]")
+    traj = traj.contiguous()
+    n = traj.numel() // TRAJ_BYTES
+    out = torch.empty(traj.shape[:-1] + (TRAJ_PACKED_BYTES,), dtype=torch.uint8, device=dev)
+    check(L.ddz_pack_trajectory(dev.index, _p(traj), n, _p(out), _stream(dev)))
+    return out
+
+
 def get_moves(hands, lasts, want_ids=True, row_capacity=None, native_joker_kickers=False):
     """Batched r.get_moves(hand15, last15) (envi.py:111): hands/lasts int8 [n,15|16] on the
     GPU.  Returns (offsets[n+1] i32, rows[total,16] i8, ids[total] i32 | None); one host sync

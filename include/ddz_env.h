@@ -41,7 +41,7 @@ extern "C" {
 #define DDZ_ECAP (-4)     /* row capacity cannot be indexed with int32     */
 #define DDZ_ENODEV (-5)   /* no usable gfx950 device                       */
 
-/* state fields: state is DDZ_NFIELDS arrays of [T][16] bytes, field-major.
+/* state fields: state is uint8 [T][DDZ_NFIELDS][16], table-major (the 11 rows of a table are 176 contiguous bytes).
  *   0..2  hand of role 0 up / 1 lord / 2 down (envi.py:24); byte 15 = cards left (envi.py:23)
  *   3..5  history: cumulative cards played by the role (envi.py:41)
  *   6..8  recent_handout of the role, zeros for a pass (envi.py:43); byte 15 = category
@@ -188,6 +188,18 @@ int ddz_select(ddz_env_t* env, const float* q, const int32_t* offsets, double ep
 /* ddz_select for the slab layout: q is f32 [T][stride] (values beyond counts[t] are ignored). */
 int ddz_select_slab(ddz_env_t* env, const float* q, const int32_t* counts, int64_t stride, double epsilon,
                     int32_t* choice, void* stream);
+
+/* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
+ * (rule_based/utils/card.py:34-159 order), device memory. */
+int ddz_action_table(int device_id, int8_t* rows, void* stream);
+
+/* 32-byte trajectory records -> 8-byte records (for the end-of-batch gather over xGMI: 4x fewer bytes).
+ *   word 0: action id (14 bits; 0x3FFF = not an action) | n_legal << 14 (9 bits) | role << 23 (2) | done << 25 |
+ *           reward code << 26 (0: 0, 1: +1, 2: -1) | flags << 28 (bit0 illegal, bit1 frozen)
+ *   word 1: choice + 1 (10 bits) | ply << 10 (8 bits) | episode << 18 (low 14 bits)
+ * traj: u8[n][32], packed: u8[n][8], device memory. */
+#define DDZ_TRAJ_PACKED_BYTES 8
+int ddz_pack_trajectory(int device_id, const uint8_t* traj, int64_t n_records, uint8_t* packed, void* stream);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */

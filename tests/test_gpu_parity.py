@@ -741,3 +741,38 @@ def test_get_moves_random_sweep(pkg, oracle, golden):
         want = oracle.legal(hands[i], lasts[i] if lasts[i].any() else None)
         assert np.array_equal(ids[offsets[i]:offsets[i + 1]], want), (i, hands[i], lasts[i])
     assert np.array_equal(rows.cpu().numpy()[:, :15], table["rows"][ids])
+
+
+def test_action_table_and_compact_trajectory(pkg, golden):
+    """ddz_action_table == the reference's action space (G1); ddz_pack_trajectory: every field of the 32-byte
+    record is recoverable from the 8-byte one (the action through its id and the table)."""
+    import importlib
+    ddist = importlib.import_module("doudizhu-rl_amd.dist")
+    table = golden("action_table.npz")
+    rows = pkg.action_table(_dev())
+    assert rows.shape == (NA, 16)
+    assert np.array_equal(rows[:, :15].cpu().numpy(), table["rows"])
+    assert np.array_equal(rows[:, 15].cpu().numpy().astype(np.uint8), table["cat_range"])
+    assert pkg.action_table(_dev(), native_joker_kickers=True).shape == (NA + 24, 16)
+    T, K = 1200, 120
+    env = pkg.BatchedEnv(T, seed=13, device=_dev())
+    env.reset()
+    traj = torch.zeros((K, T, 32), dtype=torch.uint8, device=_dev())
+    for k in range(K):   # some iterations without auto-reset: frozen records appear
+        env.step(None, pkg.STEP_RANDOM, auto_reset=(k % 40 < 30), traj=traj[k])
+        if k % 40 == 39:
+            env.reset(mask=env.field(10)[:, 1] != 0)
+    packed = pkg.pack_trajectory(traj)
+    assert packed.shape == (K, T, 8) and packed.dtype == torch.uint8
+    full = ddist.unpack_trajectory(traj)
+    comp = ddist.unpack_trajectory(packed, action_rows=rows)
+    for key in ("n_legal", "role", "done", "reward", "flags", "choice", "ply"):
+        assert torch.equal(full[key], comp[key]), key
+    assert torch.equal(full["episode"] & 0x3FFF, comp["episode"])
+    assert torch.equal(comp["row"][..., :15], full["row"][..., :15])
+    played = (full["flags"] == 0)
+    assert int((comp["id"] == 0x3FFF).sum()) == 0 and bool(played.any()) and bool((full["flags"] & 2).any())
+    assert torch.equal(comp["row"][..., 15][played], full["row"][..., 15][played])
+    # single-process gather (world 1): compact=True returns the packed form
+    g = ddist.gather_trajectories(traj, compact=True)
+    assert torch.equal(g, packed)
