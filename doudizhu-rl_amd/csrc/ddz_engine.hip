@@ -1487,6 +1487,9 @@ struct ddz_env {
 
 namespace {
 inline bool good(const ddz_env* e) { return e && e->magic == MAGIC; }
+// buffers moved as 16-byte (rows, records, planes, masks) / 8-byte / 4-byte words: a misaligned pointer from the
+// caller would be a device memory fault, so it is an argument error instead (null = optional buffer, fine)
+inline bool al(const void* p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
 struct Io {  // optional buffers of one k_table launch
   const void* sel = nullptr;
@@ -1613,6 +1616,7 @@ int ddz_reset(ddz_env_t* e, const uint8_t* mask, void* stream) {
 
 int ddz_legal(ddz_env_t* e, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(offsets, 4) || !al(ids, 4)) return DDZ_EINVAL;
   if (!offsets || !rows || cap < 0) return DDZ_EINVAL;
   if (cap > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
@@ -1628,6 +1632,7 @@ int ddz_legal(ddz_env_t* e, int32_t* offsets, int8_t* rows, int32_t* ids, int64_
 int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, const int8_t* rows, int auto_reset,
              uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(offsets, 4) || !al(traj, 16) || (mode == DDZ_STEP_ROWS ? !al(sel, 16) : !al(sel, 4))) return DDZ_EINVAL;
   if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_ROWS || !offsets || !rows) return DDZ_EINVAL;
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
@@ -1645,6 +1650,7 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
 
 int ddz_legal_slab(ddz_env_t* e, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4)) return DDZ_EINVAL;
   if (!counts || !rows || stride <= 0) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1656,6 +1662,7 @@ int ddz_legal_slab(ddz_env_t* e, int32_t* counts, int8_t* rows, int32_t* ids, in
 int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
                   int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || (mode == DDZ_STEP_ROWS ? !al(sel, 16) : !al(sel, 4))) return DDZ_EINVAL;
   if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_ROWS || !counts || !rows || stride <= 0) return DDZ_EINVAL;
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
@@ -1675,6 +1682,7 @@ int ddz_mask_words(void) { return MASK_WORDS; }
 
 int ddz_legal_mask(ddz_env_t* e, uint32_t* mask, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(mask, 16)) return DDZ_EINVAL;
   if (!mask) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1685,6 +1693,7 @@ int ddz_legal_mask(ddz_env_t* e, uint32_t* mask, void* stream) {
 
 int ddz_observe(ddz_env_t* e, int variant, float* face, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(face, 16)) return DDZ_EINVAL;
   const int P = ddz_face_planes(variant);
   if (P < 0 || !face) return DDZ_EINVAL;
   DeviceGuard g(e->device);
@@ -1702,6 +1711,7 @@ int ddz_observe(ddz_env_t* e, int variant, float* face, void* stream) {
 }
 
 int ddz_rows_to_onehot(int device, const int8_t* rows, int64_t n, float* out, void* stream) {
+  if (!al(rows, 16) || !al(out, 16)) return DDZ_EINVAL;
   if (n < 0 || (n > 0 && (!rows || !out))) return DDZ_EINVAL;
   if (n == 0) return DDZ_OK;
   DeviceGuard g(device);
@@ -1714,6 +1724,7 @@ int ddz_rows_to_onehot(int device, const int8_t* rows, int64_t n, float* out, vo
 
 int ddz_get_moves(int device, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* offsets, int8_t* rows,
                   int32_t* ids, int64_t cap, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!al(hands, 16) || !al(lasts, 16) || !al(rows, 16) || !al(offsets, 4) || !al(ids, 4) || !al(scratch, 16)) return DDZ_EINVAL;
   if (n <= 0 || !hands || !lasts || !offsets || !rows || !scratch || cap < 0) return DDZ_EINVAL;
   if (cap > 0x7FFFFFFF) return DDZ_ECAP;
   const Layout l = make_layout(n);
@@ -1727,6 +1738,7 @@ int ddz_get_moves(int device, const int8_t* hands, const int8_t* lasts, int64_t 
 
 int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(stats, 8)) return DDZ_EINVAL;
   if (!stats) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1759,6 +1771,7 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
 int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
                        int64_t* stats, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || !al(stats, 8)) return DDZ_EINVAL;
   if (n_iters < 0 || !counts || !rows || stride < 1) return DDZ_EINVAL;
   if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
@@ -1778,6 +1791,7 @@ int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* r
 int ddz_rollout_random_csr(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8_t* rows, int32_t* ids, int64_t cap,
                            uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(offsets, 4) || !al(ids, 4) || !al(traj, 16)) return DDZ_EINVAL;
   if (n_iters < 0 || !offsets || !rows || cap < 0) return DDZ_EINVAL;
   if (cap > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
@@ -1799,6 +1813,7 @@ int ddz_rollout_random_csr(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8
 int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids,
                              int64_t stride, double* ms, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4)) return DDZ_EINVAL;
   if (n_iters <= 0 || !counts || !rows || stride < 1 || !ms) return DDZ_EINVAL;
   if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
@@ -1841,6 +1856,7 @@ int ddz_debug_set_stamps(void* buf) {
 
 int ddz_select(ddz_env_t* e, const float* q, const int32_t* offsets, double epsilon, int32_t* choice, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(q, 4) || !al(offsets, 4) || !al(choice, 4)) return DDZ_EINVAL;
   if (!q || !offsets || !choice || !(epsilon >= 0.0) || epsilon > 1.0) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1854,6 +1870,7 @@ int ddz_select(ddz_env_t* e, const float* q, const int32_t* offsets, double epsi
 int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t stride, double epsilon, int32_t* choice,
                     void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
+  if (!al(q, 4) || !al(counts, 4) || !al(choice, 4)) return DDZ_EINVAL;
   if (!q || !counts || stride <= 0 || !choice || !(epsilon >= 0.0) || epsilon > 1.0) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1865,6 +1882,7 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
 }
 
 int ddz_action_table(int device, int8_t* rows, void* stream) {
+  if (!al(rows, 16)) return DDZ_EINVAL;
   if (!rows) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1876,6 +1894,7 @@ int ddz_action_table(int device, int8_t* rows, void* stream) {
 }
 
 int ddz_pack_trajectory(int device, const uint8_t* traj, int64_t n_records, uint8_t* packed, void* stream) {
+  if (!al(traj, 16) || !al(packed, 8)) return DDZ_EINVAL;
   if (n_records < 0 || (n_records > 0 && (!traj || !packed))) return DDZ_EINVAL;
   if (n_records == 0) return DDZ_OK;
   DeviceGuard g(device);
@@ -1889,6 +1908,7 @@ int ddz_pack_trajectory(int device, const uint8_t* traj, int64_t n_records, uint
 
 // debug/test entry: classify(rows) -> info words (category | value << 8 | len << 16, 0xFF invalid)
 int ddz_debug_classify(int device, const int8_t* rows, int64_t n, uint32_t* out, void* stream) {
+  if (!al(rows, 16) || !al(out, 4)) return DDZ_EINVAL;
   if (n <= 0 || !rows || !out) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;

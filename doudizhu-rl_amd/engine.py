@@ -168,6 +168,8 @@ class BatchedEnv:
         P = FACE_PLANES[variant]
         if out is None:
             out = torch.empty((self.T, P, 15, 4), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.numel() != self.T * P * 60 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 [T,{P},15,4] tensor")
         check(self.lib.ddz_observe(self._h, int(variant), _p(out), _stream(self.device)))
         return out
 

@@ -776,3 +776,19 @@ def test_action_table_and_compact_trajectory(pkg, golden):
     # single-process gather (world 1): compact=True returns the packed form
     g = ddist.gather_trajectories(traj, compact=True)
     assert torch.equal(g, packed)
+
+
+def test_misaligned_buffers_are_argument_errors(pkg):
+    """Rows / records / planes move as 16-byte words: a misaligned caller pointer is DDZ_EINVAL, not a fault."""
+    raw = torch.zeros(64 * 16 + 16, dtype=torch.int8, device=_dev())
+    bad = raw[1:1 + 64 * 16].view(64, 16)
+    assert bad.data_ptr() % 16 != 0
+    with pytest.raises(pkg.DdzError):
+        pkg.rows_to_onehot(bad)
+    env = pkg.BatchedEnv(64, seed=1, device=_dev())
+    env.reset()
+    rawf = torch.zeros(64 * 6 * 60 + 4, dtype=torch.float32, device=_dev())
+    with pytest.raises(pkg.DdzError):
+        env.observe(3, out=rawf[1:1 + 64 * 6 * 60].view(64, 6, 15, 4))
+    assert env.status() == 0
+    env.observe(3)  # the handle is still fine
