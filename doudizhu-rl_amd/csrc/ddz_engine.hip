@@ -1,7 +1,12 @@
 // ddz_engine.hip -- gfx950 kernels + C ABI (include/ddz_env.h) of the batched Doudizhu engine.
 //
 // Kernel map (reference paths relative to /root/reference):
-//   k_table   ONE WAVEFRONT PER TABLE, the whole lock-step iteration in one launch:
+//   k_rollout THE DOMINANT KERNEL (ddz_rollout_random): one wavefront per table, all lock-step iterations of a
+//             random-policy rollout (game.py:169-181 with envi.py:79-85) inside one launch, state in registers,
+//             lists in fixed-stride slabs; arithmetic fast path for follows of singles / pairs / triples, planner
+//             + LDS staging list for the rest (see the comment at the kernel).
+//   k_table   ONE WAVEFRONT PER TABLE, one lock-step iteration per launch (the API a policy drives; CSR lists,
+//             or slab lists with F_SLAB = apply + enumerate in the same launch):
 //             lanes 0..10 load the table's 11 packed rows (176 contiguous bytes), then
 //             [enumerate] the combo enumerator + follow filter (r.get_moves, envi.py:111;
 //                 rules utils.py:45-63 get_mask, card.py:307-325 bigger_than) as a pruned
@@ -21,6 +26,8 @@
 //   k_build_table  fills the record table once per device with the structural enumerator
 //             (rank masks -> rows/ids in closed form), itself pinned by the golden tests.
 //   k_observe the `face` tensors (envi.py:87-96,165-217), k_onehot batch_arr2onehot (:139-146).
+//   k_mask    get_mask (utils.py:45-63) of every table as a bit-packed dense mask; k_select segment arg-max /
+//             epsilon-greedy (dqn.py:50-71); k_pack_traj 32-byte -> 8-byte trajectory records; k_export_table.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
