@@ -107,7 +107,7 @@ struct Out {
   uint64_t* stage;      // EM_STAGE: per-wave LDS list of nib | category << 60, in id order,
   uint16_t* stage_vl;   //           value | len << 8 of each entry (card.py:327-335)
   uint16_t* stage_ids;  //           and (IDS) the canonical ids
-  uint32_t* mask;       // EM_MASK: per-wave LDS bit mask over the action space (bit id)
+  uint32_t* mask = nullptr;  // EM_MASK: per-wave LDS bit mask over the action space (bit id)
 };
 // what a scan does with the legal lanes
 constexpr int EM_COUNT = 0;   // nothing (list size only)
