@@ -792,3 +792,31 @@ def test_misaligned_buffers_are_argument_errors(pkg):
         env.observe(3, out=rawf[1:1 + 64 * 6 * 60].view(64, 6, 15, 4))
     assert env.status() == 0
     env.observe(3)  # the handle is still fine
+
+
+def test_bench_contract():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object (HIP-event launch duration, PMC
+    traffic) and, at N = 1, the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "300", "--warmup", "30",
+                        "--cpu-budget", "1.5"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 300 and j["warmup"] == 30 and j["higher_is_better"] is True
+    assert j["unit"] == "env steps/s" and j["dtype"] == "u8" and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["value"] > 1e8 and abs(j["ms_per_step"] * 1e-3 * j["value"] - 4096) < 1
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 4096 * 300
+    assert "workload" in j["config"] and "model" not in j["config"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c
