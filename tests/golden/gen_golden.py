@@ -17,6 +17,8 @@ source.  Usage:  python tests/golden/gen_golden.py [--quick]
                        ply's legal set cross-checked against the reference mask
                        at generation time (deal / RNG are spec v1 of this repo)
   G5 thermo.npz        Card.char2onehot60 (card.py:184-192) of every action row
+  G6 legal_sweep.npz   4,000 uniformly random cases -- hands of 1..20 random cards, `last` uniform over the whole
+                       action space (or a lead, 1 in 5) -- through the same reference functions as G3
 """
 import argparse
 import os
@@ -214,12 +216,30 @@ def gen_g5(rows):
     np.savez_compressed(os.path.join(HERE, "thermo.npz"), bits=np.packbits(bits, axis=1))
 
 
+def _g6_case(args):
+    return ref_legal_ids(*args)
+
+
+def gen_g6(rows, n_cases, seed):
+    import multiprocessing as mp
+    rng = np.random.default_rng(seed)
+    hands = np.stack([random_hand(rng, int(rng.integers(1, 21))) for _ in range(n_cases)])
+    lasts = rng.integers(1, NA, n_cases).astype(np.int32)
+    lasts[np.arange(n_cases) % 5 == 0] = 0
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        legal = pool.map(_g6_case, [(hands[i], int(lasts[i])) for i in range(n_cases)], chunksize=25)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in legal])]).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "legal_sweep.npz"), hands=hands, last_ids=lasts, offsets=offs,
+                        ids=np.concatenate(legal).astype(np.int16))
+    return n_cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="small fixture set (smoke of this script)")
     ap.add_argument("--only", default="", help="comma list of g1..g5")
     a = ap.parse_args()
-    only = set(a.only.split(",")) if a.only else {"g1", "g2", "g3", "g4", "g5"}
+    only = set(a.only.split(",")) if a.only else {"g1", "g2", "g3", "g4", "g5", "g6"}
     rng = np.random.default_rng(20261004)
     t0 = time.time()
     rows, cat_range, groups = gen_g1()
@@ -236,6 +256,9 @@ def main():
     if "g5" in only:
         gen_g5(rows)
         print(f"G5 thermometer ({time.time() - t0:.0f}s)", flush=True)
+    if "g6" in only:
+        n = gen_g6(rows, 200 if a.quick else 4000, seed=20261005)
+        print(f"G6 legal sweep: {n} cases ({time.time() - t0:.0f}s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -75,6 +75,18 @@ def test_get_moves_golden_cases(pkg, golden):
     assert np.array_equal(rows[:, 15].astype(np.uint8), table["cat_range"][g["ids"].astype(np.int64)])
 
 
+def test_get_moves_golden_sweep(pkg, golden):
+    """G6 through ddz_get_moves: 4,000 random (hand, last) pairs vs the reference's get_mask_onehot60 outputs."""
+    g = golden("legal_sweep.npz")
+    table = golden("action_table.npz")
+    hands = torch.from_numpy(g["hands"]).to(_dev())
+    lasts = torch.from_numpy(table["rows"][g["last_ids"]]).to(_dev())
+    offsets, rows, ids = pkg.get_moves(hands, lasts)
+    assert np.array_equal(offsets.cpu().numpy(), g["offsets"])
+    assert np.array_equal(ids.cpu().numpy(), g["ids"].astype(np.int32))
+    assert np.array_equal(rows.cpu().numpy()[:, :15], table["rows"][g["ids"].astype(np.int64)])
+
+
 def test_get_moves_rejects_bad_last(pkg):
     hands = torch.tensor([[4] * 13 + [1, 1]], dtype=torch.int8, device=_dev())
     lasts = torch.zeros((1, 15), dtype=torch.int8, device=_dev())

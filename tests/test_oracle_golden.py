@@ -56,6 +56,19 @@ def test_legal_cases_match_get_mask(oracle, golden):
     assert seen_cats == set(range(15))
 
 
+def test_legal_sweep_matches_get_mask(oracle, golden):
+    """G6: 4,000 uniformly random (hand, last) pairs, `last` uniform over the whole action space, legal ids by
+    the reference's get_mask_onehot60."""
+    g = golden("legal_sweep.npz")
+    rows, _ = oracle.action_table()
+    n = len(g["hands"])
+    assert n == 4000 and (g["last_ids"] == 0).sum() == 800
+    for k in range(n):
+        lid = int(g["last_ids"][k])
+        mine = oracle.legal(g["hands"][k], None if lid == 0 else rows[lid, :15])
+        assert np.array_equal(mine, g["ids"][g["offsets"][k]:g["offsets"][k + 1]].astype(np.int32)), f"case {k}"
+
+
 def test_philox_known_answers(oracle):
     # Random123 kat_vectors, philox4x32-10
     kat = [
