@@ -4,7 +4,7 @@ terminal/reward, state encoding).  HIP kernels + C ABI under csrc/, host mirror 
 reference's envi.py here.  Import never touches the GPU; using the engine without the
 built library or without an MI355X raises (there is no CPU fallback)."""
 from ._lib import DdzError  # noqa: F401
-from .engine import (BatchedEnv, FACE_PLANES, NUM_ACTIONS, STEP_CHOICE, STEP_RANDOM,  # noqa: F401
-                     STEP_ROWS, TRAJ_BYTES, TRAJ_PACKED_BYTES, action_table, get_moves, pack_trajectory,
-                     rows_to_onehot)
+from .engine import (BatchedEnv, FACE_PLANES, NUM_ACTIONS, STEP_CHOICE, STEP_IDS, STEP_RANDOM,  # noqa: F401
+                     STEP_ROWS, TRAJ_BYTES, TRAJ_PACKED_BYTES, action_table, auto_choose, cards_value, get_moves,
+                     pack_trajectory, rows_to_onehot)
 from .envi import Env, EnvComplicated, EnvCooperation, EnvCooperationSimplify  # noqa: F401

@@ -158,6 +158,13 @@ constexpr int CL_N[9] = {91, 78, 66, 55, 220, 120, 330, 126, 252};
 constexpr int CL_OFF[10] = {0, 91, 169, 235, 290, 510, 630, 960, 1086, 1338};
 constexpr int COMBO_WORDS = 1338;
 __device__ uint32_t g_combo[COMBO_WORDS];
+// the 16-byte row (counts + category) of a canonical action id, including the joker-kicker extras of that build
+__device__ __forceinline__ uint4 row_of_id(int id) {
+  if (id < DDZ_NUM_ACTIONS) return g_tab[2 * id];
+  const int k = id - DDZ_NUM_ACTIONS;  // 0..12 quad + jokers, 13..23 two triples + jokers
+  const uint64_t jk = (1ull << 52) | (1ull << 56);
+  return k < 13 ? unpack_row((4ull << (4 * k)) | jk, FOUR_TAKE_ONE) : unpack_row((0x33ull << (4 * (k - 13))) | jk, THREE_ONE_LINE);
+}
 __device__ uint4 g_tmp_rows[DDZ_NUM_ACTIONS];
 __device__ int32_t g_tmp_ids[DDZ_NUM_ACTIONS];
 
@@ -503,6 +510,8 @@ __device__ __forceinline__ uint32_t last_info(uint64_t n1, int c1, uint64_t n2, 
   return mk_info(EMPTY, 0, 1);
 }
 
+#include "ddz_auto.h"
+
 // DDZ_STAMP: diagnostic build only (tools/stamp_probe.py): k_rollout accumulates s_memtime
 // deltas per phase into a debug buffer nothing else reads.
 #ifdef DDZ_STAMP
@@ -633,8 +642,10 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       const bool frozen = !active || A <= 0;
       int idx = -1;
       uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // the chosen row, wave-uniform
+      int32_t sel_id = 0;  // DDZ_STEP_IDS: canonical action id, -1 = engine RNG
+      if (MODE == DDZ_STEP_IDS) sel_id = (int32_t)rfl((uint32_t)((const int32_t*)a.sel)[t]);
       if (!frozen) {
-        if (MODE == DDZ_STEP_RANDOM) {
+        if (MODE == DDZ_STEP_RANDOM || (MODE == DDZ_STEP_IDS && sel_id == -1)) {
           if (PICK) {
             idx = pk.want; c0 = pk.r0; c1 = pk.r1; c2 = pk.r2; c3 = pk.r3;
           } else {
@@ -649,8 +660,10 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
             if (idx < 0 || idx >= A) idx = -1;
           }
         } else {  // wave-parallel search of the segment for the wanted counts
-          const uint4 want = ((const uint4*)a.sel)[t];
-          for (int j0 = 0; j0 < A && idx < 0; j0 += 64) {
+          constexpr int NIDS = DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS;
+          const bool id_ok = MODE != DDZ_STEP_IDS || (sel_id >= 0 && sel_id < NIDS);
+          const uint4 want = MODE == DDZ_STEP_IDS ? row_of_id(id_ok ? sel_id : 0) : ((const uint4*)a.sel)[t];
+          for (int j0 = 0; j0 < A && idx < 0 && id_ok; j0 += 64) {
             bool hit = false;
             if (j0 + lane < A) {
               const uint4 r = a.rows[off + j0 + lane];
@@ -1336,14 +1349,7 @@ __device__ int32_t g_sorted_id[NUM_ACTIONS_X];    // ... and their canonical ids
 __global__ __launch_bounds__(BLOCK) void k_export_table(uint4* __restrict__ rows) {
   const int id = (int)(blockIdx.x * BLOCK + threadIdx.x);
   if (id >= NUM_ACTIONS_X) return;
-  if (id < DDZ_NUM_ACTIONS) {
-    rows[id] = g_tab[2 * id];
-    return;
-  }
-  const int k = id - DDZ_NUM_ACTIONS;  // 0..12 quad + jokers, 13..23 two triples + jokers
-  const uint64_t jk = (1ull << 52) | (1ull << 56);
-  rows[id] = k < 13 ? unpack_row((4ull << (4 * k)) | jk, FOUR_TAKE_ONE)
-                    : unpack_row((0x33ull << (4 * (k - 13))) | jk, THREE_ONE_LINE);
+  rows[id] = row_of_id(id);
 }
 
 // 32-byte trajectory record -> 8 bytes (what has to cross xGMI): the action as its canonical id
@@ -1640,7 +1646,7 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
              uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(offsets, 4) || !al(traj, 16) || (mode == DDZ_STEP_ROWS ? !al(sel, 16) : !al(sel, 4))) return DDZ_EINVAL;
-  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_ROWS || !offsets || !rows) return DDZ_EINVAL;
+  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_IDS || !offsets || !rows) return DDZ_EINVAL;
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1651,6 +1657,7 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
   switch (mode) {
     case DDZ_STEP_RANDOM: return launch_table<F_STEP, DDZ_STEP_RANDOM>(e, io, st);
     case DDZ_STEP_CHOICE: return launch_table<F_STEP, DDZ_STEP_CHOICE>(e, io, st);
+    case DDZ_STEP_IDS: return launch_table<F_STEP, DDZ_STEP_IDS>(e, io, st);
     default: return launch_table<F_STEP, DDZ_STEP_ROWS>(e, io, st);
   }
 }
@@ -1670,7 +1677,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
                   int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || (mode == DDZ_STEP_ROWS ? !al(sel, 16) : !al(sel, 4))) return DDZ_EINVAL;
-  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_ROWS || !counts || !rows || stride <= 0) return DDZ_EINVAL;
+  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_IDS || !counts || !rows || stride <= 0) return DDZ_EINVAL;
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1681,6 +1688,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   switch (mode) {
     case DDZ_STEP_RANDOM: return launch_table<F_STEP | F_SLAB, DDZ_STEP_RANDOM>(e, io, st);
     case DDZ_STEP_CHOICE: return launch_table<F_STEP | F_SLAB, DDZ_STEP_CHOICE>(e, io, st);
+    case DDZ_STEP_IDS: return launch_table<F_STEP | F_SLAB, DDZ_STEP_IDS>(e, io, st);
     default: return launch_table<F_STEP | F_SLAB, DDZ_STEP_ROWS>(e, io, st);
   }
 }
@@ -1842,6 +1850,50 @@ int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int
   (void)hipEventDestroy(ev[0]);
   (void)hipEventDestroy(ev[1]);
   return rc;
+}
+
+static void fill_round_penalty(AutoArgs& a) {
+  // rule_based_model.py:57: round_penalty = 15 - 12 * min_oppo_cards / 20 (Python: int product, true division)
+  for (int m = 0; m < 24; ++m) a.rp[m] = 15 - 12 * m / 20.0;
+}
+
+int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* stats, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!ids || !al(ids, 4) || !al(stats, 8) || auto_roles < 0 || auto_roles > 7) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  AutoArgs a{};
+  a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
+  a.status = e->sc.status;
+  fill_round_penalty(a);
+  hipLaunchKernelGGL(k_auto<true>, dim3((unsigned)((e->T + WPB - 1) / WPB)), dim3(TB), 0, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n, int32_t* ids,
+                    int64_t* stats, void* stream) {
+  if (!al(hands, 16) || !al(lasts, 16) || !al(info, 4) || !al(ids, 4) || !al(stats, 8)) return DDZ_EINVAL;
+  if (n <= 0 || n > ((int64_t)1 << 30) || !hands || !lasts || !info || !ids) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  AutoArgs a{};
+  a.hands = (const uint4*)hands; a.lasts = (const uint4*)lasts; a.info = (const uint32_t*)info;
+  a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = nullptr;
+  fill_round_penalty(a);
+  hipLaunchKernelGGL(k_auto<false>, dim3((unsigned)((n + WPB - 1) / WPB)), dim3(TB), 0, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int ddz_debug_cards_value(int device, int8_t* out, void* stream) {
+  if (!out) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cards_value, dim3((DDZ_NUM_ACTIONS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, out);
+  return check_launch();
 }
 
 int ddz_status(ddz_env_t* e, int32_t* out, void* stream) {

@@ -16,7 +16,7 @@ ROW = 16
 NFIELDS = 11
 TRAJ_BYTES = 32
 NUM_ACTIONS = 13527
-STEP_RANDOM, STEP_CHOICE, STEP_ROWS = 0, 1, 2
+STEP_RANDOM, STEP_CHOICE, STEP_ROWS, STEP_IDS = 0, 1, 2, 3
 FACE_PLANES = (4, 7, 9, 6)  # Env, EnvComplicated, EnvCooperation, EnvCooperationSimplify
 F_HAND0, F_HIST0, F_RECENT0, F_TAKEN, F_META = 0, 3, 6, 9, 10
 # a 20-card hand never has more than this many legal moves (tests/test_rules_bounds.py);
@@ -126,13 +126,14 @@ class BatchedEnv:
     def step(self, sel=None, mode=STEP_CHOICE, auto_reset=True, traj=None):
         """Apply one action per table (envi.py:63-70 step_manual / :79-85 step_random).
         mode STEP_RANDOM: sel ignored; STEP_CHOICE: sel int32[T] index into each legal
-        segment; STEP_ROWS: sel int8[T,16] count rows.  Returns (done u8[T], r i8[T],
+        segment; STEP_ROWS: sel int8[T,16] count rows; STEP_IDS: sel int32[T] canonical action ids
+        (-1 = engine RNG for that table), what auto_choose() returns.  Returns (done u8[T], r i8[T],
         illegal u8[T]); r = -1 lord won, +1 farmers won (rule_play.py:14)."""
         self._need_legal()
-        if mode == STEP_CHOICE:
+        if mode in (STEP_CHOICE, STEP_IDS):
             sel = sel.to(device=self.device, dtype=torch.int32).contiguous()
             if sel.numel() != self.T:
-                raise ValueError("choice must have one index per table")
+                raise ValueError("choice / ids must have one entry per table")
         elif mode == STEP_ROWS:
             sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
             if tuple(sel.shape) != (self.T, ROW):
@@ -162,6 +163,27 @@ class BatchedEnv:
 
     def step_random(self, auto_reset=True, traj=None):
         return self.step(None, STEP_RANDOM, auto_reset, traj)
+
+    # ---- rule-based opponent (envi.py:72-77 step_auto) ----
+    def auto_choose(self, auto_roles=0b101, out=None, stats=None):
+        """The rule agent's move (RuleBasedModel.choose, rule_based/utils/rule_based_model.py:43-101) for every table
+        whose actor's role bit is set in auto_roles (bit 0 up, 1 lord, 2 down; default: both farmers): int32[T]
+        canonical action ids, -1 for the other tables.  stats: optional int64 [T,2] {combinations, search nodes}."""
+        if out is None:
+            out = torch.empty(self.T, dtype=torch.int32, device=self.device)
+        if stats is not None and (stats.dtype != torch.int64 or stats.numel() != 2 * self.T or not stats.is_contiguous()):
+            raise ValueError("stats must be a contiguous int64 [T,2] tensor")
+        check(self.lib.ddz_auto_choose_state(self._h, int(auto_roles), _p(out), _p(stats), _stream(self.device)))
+        return out
+
+    def step_auto(self, auto_roles=0b101, ids=None, auto_reset=True, traj=None, slab=False):
+        """One lock-step iteration in which the roles of auto_roles are played by the rule agent (Env.step_auto,
+        envi.py:72-77) and every other table moves by `ids` (int32[T] canonical action ids of a policy; None or -1 =
+        engine RNG, i.e. step_random).  game.py:106: `_, done, _ = self.env.step_auto()` for a role without a network."""
+        sel = self.auto_choose(auto_roles)
+        if ids is not None:
+            sel = torch.where(sel >= 0, sel, ids.to(device=self.device, dtype=torch.int32))
+        return (self.step_slab if slab else self.step)(sel, STEP_IDS, auto_reset, traj)
 
     def observe(self, variant=3, out=None):
         """`face` of every table: f32 [T,P,15,4] (envi.py:87-96,165-217)."""
@@ -254,10 +276,10 @@ class BatchedEnv:
         states (game.py:95-106 + envi.py:98-116).  Returns (done, r, illegal) like step()."""
         if not self._slab_fresh:
             self.legal_slab()
-        if mode == STEP_CHOICE:
+        if mode in (STEP_CHOICE, STEP_IDS):
             sel = sel.to(device=self.device, dtype=torch.int32).contiguous()
             if sel.numel() != self.T:
-                raise ValueError("choice must have one index per table")
+                raise ValueError("choice / ids must have one entry per table")
         elif mode == STEP_ROWS:
             sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
             if tuple(sel.shape) != (self.T, ROW):
@@ -414,3 +436,36 @@ def get_moves(hands, lasts, want_ids=True, row_capacity=None, native_joker_kicke
     if bad:
         raise ValueError("a `last` vector is not a combo of the action space")
     return offsets, rows[:total], (ids[:total] if want_ids else None)
+
+
+def auto_choose(hands, lasts, left, role, want_stats=False):
+    """RuleBasedModel.choose for n independent queries (what server/core.py:80-87 calls on a payload): hands / lasts
+    int8 [n,15|16] (last all-zero = lead), left int [n,3] = cards left of role 0 up / 1 lord / 2 down, role int [n].
+    Returns int32[n] canonical action ids (0 = pass, -1 = invalid query) (and int64 [n,2] {combinations, nodes})."""
+    L = _lib.lib()
+    dev = _require_gpu(hands.device)
+
+    def pad(x):
+        x = x.to(device=dev, dtype=torch.int8)
+        if x.shape[1] == 15:
+            x = torch.nn.functional.pad(x, (0, 1))
+        return x.contiguous()
+
+    hands, lasts = pad(hands), pad(lasts)
+    n = hands.shape[0]
+    info = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    info[:, :3] = torch.as_tensor(left, device=dev).reshape(n, 3).to(torch.uint8)
+    info[:, 3] = torch.as_tensor(role, device=dev).reshape(n).to(torch.uint8)
+    ids = torch.empty(n, dtype=torch.int32, device=dev)
+    stats = torch.zeros((n, 2), dtype=torch.int64, device=dev) if want_stats else None
+    check(L.ddz_auto_choose(dev.index, _p(hands), _p(lasts), _p(info), n, _p(ids), _p(stats), _stream(dev)))
+    return (ids, stats) if want_stats else ids
+
+
+def cards_value(device="cuda:0"):
+    """cards_value of rule_based/utils/evaluator.py:10-47 for every action id, float64 [13527] (device test hook)."""
+    L = _lib.lib()
+    dev = _require_gpu(device)
+    out = torch.empty(NUM_ACTIONS, dtype=torch.int8, device=dev)
+    check(L.ddz_debug_cards_value(dev.index, _p(out), _stream(dev)))
+    return out.to(torch.float64) / 2.0

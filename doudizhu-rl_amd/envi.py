@@ -4,9 +4,10 @@ by a one-table BatchedEnv on the MI355X instead of the absent pybind modules `en
 (envi.py:10-13).  This is the N = 1 compatibility view for the existing game.py / dqn.py
 loop; throughput comes from BatchedEnv, which these classes wrap.
 
-Differences that cannot be avoided (documented in DESIGN.md): the deal / RNG and the two
-probability planes of `face` are this repo's spec v1 because the native code that defined
-them is not in the reference; step_auto (the native rule-based opponent) is not built yet.
+Differences that cannot be avoided (documented in DESIGN.md 4): the deal / RNG (spec v2) and the two
+probability planes of `face` (spec v1) are this repo's definitions because the native code that defined
+them is not in the reference; step_auto plays the reference's Python rule agent (rule_based_model.py) over
+"decomposer spec v1" in place of the absent native decomposition functions.
 """
 import collections
 import random
@@ -15,7 +16,7 @@ import numpy as np
 import torch
 
 from . import config as conf
-from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE,
+from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE, STEP_IDS,
                      rows_to_onehot)
 
 
@@ -53,7 +54,7 @@ class Env:
         self._clear()
 
     def prepare(self):
-        """native shuffle + deal + lord selection (game.py:171); deal = spec v1."""
+        """native shuffle + deal + lord selection (game.py:171); deal = spec v2."""
         self._b.reset()
         self._sync()
 
@@ -99,9 +100,18 @@ class Env:
         return self._apply(self._find(self.onehot2arr(onehot_cards)))
 
     def step_auto(self):
-        raise NotImplementedError(
-            "step_auto is the native rule-based opponent of the absent `env` module "
-            "(envi.py:72-77); it is row N1 of SURVEY.md section 8f and not built yet")
+        """envi.py:72-77: the rule-based opponent moves -> (cards, r, _).  The native step_auto is absent from the
+        reference; this plays RuleBasedModel.choose (rule_based/utils/rule_based_model.py:43-101) on the device
+        (decomposer spec v1)."""
+        role = self.get_role_ID() - 1
+        self.old_cards[role] = self.get_curr_handcards()
+        ids = self._b.auto_choose(0b111)
+        done, r, illegal = self._b.step(ids, STEP_IDS, auto_reset=False)
+        if int(illegal.item()):
+            raise RuntimeError("the rule agent chose an illegal action")
+        self._sync()
+        cards = self.arr2cards(self.recent_handout[role].astype(int))
+        return cards, int(r.item()), None
 
     def step_random(self):
         """envi.py:79-85 with Python's global `random` as in the reference."""

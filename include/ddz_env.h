@@ -55,6 +55,9 @@ enum { DDZ_F_HAND0 = 0, DDZ_F_HIST0 = 3, DDZ_F_RECENT0 = 6, DDZ_F_TAKEN = 9, DDZ
 #define DDZ_STEP_CHOICE 1 /* sel = const int32_t[T], index into each table's legal segment              */
 #define DDZ_STEP_ROWS 2   /* sel = const int8_t[T][16] count rows (envi.py:63-70 step_manual), validated
                              against the legal segment; no match -> illegal flag, table untouched       */
+#define DDZ_STEP_IDS 3    /* sel = const int32_t[T] canonical action ids (index into card.py:get_action_space();
+                             what ddz_auto_choose_state writes, or the arg-max of a policy head over
+                             ddz_legal_mask), validated like ROWS; -1 = engine RNG for that table (RANDOM)  */
 
 /* face variants (envi.py:87-96, :165-178, :182-198, :202-217) -> planes P = 4, 7, 9, 6 */
 #define DDZ_FACE_ENV 0
@@ -88,7 +91,7 @@ int ddz_invalidate(ddz_env_t* env);
 
 /* Replaces Env.reset() + native prepare() (envi.py:30-36, game.py:170-171): clear the
  * bookkeeping and deal 17/20/17 (lord = role 1 moves first) for every table whose mask
- * byte is non-zero (mask NULL = all).  Deal/RNG = spec v1.                */
+ * byte is non-zero (mask NULL = all).  Deal/RNG = spec v2.                */
 int ddz_reset(ddz_env_t* env, const uint8_t* table_mask, void* stream);
 
 /* Replaces Env.valid_actions(tensor=False) / r.get_moves (envi.py:98-116) for all tables:
@@ -200,6 +203,25 @@ int ddz_action_table(int device_id, int8_t* rows, void* stream);
  * traj: u8[n][32], packed: u8[n][8], device memory. */
 #define DDZ_TRAJ_PACKED_BYTES 8
 int ddz_pack_trajectory(int device_id, const uint8_t* traj, int64_t n_records, uint8_t* packed, void* stream);
+
+/* Replaces Env.step_auto (envi.py:72-77; game.py:106 for every role without a network; rule_based/rule_play.py:16-23):
+ * the move of the rule-based opponent.  The native step_auto is absent from the reference; its in-repo statement is
+ * RuleBasedModel.choose (rule_based/utils/rule_based_model.py:43-101) over Decomposer.get_combinations
+ * (rule_based/utils/decomposer.py:17-76) and cards_value (rule_based/utils/evaluator.py:10-47), which this computes
+ * -- with "decomposer spec v1"  in place of the two absent native decomposition functions.
+ *   ddz_auto_choose_state: for every table whose ACTOR's role bit is set in auto_roles (bit r = role r: 0 up, 1 lord,
+ *     2 down) ids[t] = the canonical id of the chosen action (0 = pass), for all other tables -1.  Feed ids to
+ *     ddz_step / ddz_step_slab with DDZ_STEP_IDS: rule agents move as chosen, everybody else by the engine RNG; or
+ *     merge a policy's own ids into the -1 slots first.
+ *   ddz_auto_choose: the same for n independent queries (server/core.py:80-87 calls choose() on a payload):
+ *     hands / lasts int8[n][16] (byte 15 ignored, `last` all-zero = lead), info u8[n][4] = cards left of role 0, 1, 2
+ *     (envi.py:23 `left`) and the acting role; an invalid query (no combo, role > 2) yields -1.
+ *   stats (may be NULL): int64[n][2] = {combinations scored, search nodes} per table / query.                  */
+int ddz_auto_choose_state(ddz_env_t* env, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
+int ddz_auto_choose(int device_id, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n,
+                    int32_t* ids, int64_t* stats, void* stream);
+/* test hook: 2 * cards_value (rule_based/utils/evaluator.py:10-47) of every action id, int8[DDZ_NUM_ACTIONS] */
+int ddz_debug_cards_value(int device_id, int8_t* out, void* stream);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */

@@ -385,7 +385,7 @@ void ddzo_env_step(uint8_t* s, int64_t T, uint64_t seed, uint64_t gid_base, int 
     }
     int32_t idx = -1;
     const int8_t* seg = rows + (int64_t)offsets[t] * DDZO_ROW;
-    if (mode == DDZO_STEP_RANDOM) {
+    if (mode == DDZO_STEP_RANDOM || (mode == DDZO_STEP_IDS && ((const int32_t*)sel)[t] == -1)) {
       /* random.choice(actions), envi.py:83 -> engine RNG (spec v1) */
       uint32_t ctr[4] = {(uint32_t)(gid_base + t), (uint32_t)((gid_base + t) >> 32), ep,
                          (2u << 16) | ply};
@@ -395,6 +395,11 @@ void ddzo_env_step(uint8_t* s, int64_t T, uint64_t seed, uint64_t gid_base, int 
     } else if (mode == DDZO_STEP_CHOICE) {
       idx = ((const int32_t*)sel)[t];
       if (idx < 0 || idx >= A) idx = -1;
+    } else if (mode == DDZO_STEP_IDS) { /* canonical action ids; looked up in the legal list */
+      int32_t id = ((const int32_t*)sel)[t];
+      if (id >= 0 && id < NA)
+        for (int32_t j = 0; j < A && idx < 0; ++j)
+          if (memcmp(seg + (int64_t)j * DDZO_ROW, g_rows[id], NR) == 0) idx = j;
     } else {
       const int8_t* want = (const int8_t*)sel + t * DDZO_ROW;
       for (int32_t j = 0; j < A && idx < 0; ++j)

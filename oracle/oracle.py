@@ -15,7 +15,7 @@ NUM_ACTIONS = 13527
 ROW = 16
 NFIELDS = 11
 TR_BYTES = 32
-STEP_RANDOM, STEP_CHOICE, STEP_ROWS = 0, 1, 2
+STEP_RANDOM, STEP_CHOICE, STEP_ROWS, STEP_IDS = 0, 1, 2, 3
 PLANES = (4, 7, 9, 6)
 
 _libs = {}
@@ -25,10 +25,9 @@ _jk = False  # which rule set lib() serves: False = card.py (13,527 rows), True 
 def build(force=False, jk=False):
     name = "libddz_oracle_jk.so" if jk else "libddz_oracle.so"
     so = os.path.join(HERE, name)
-    src = os.path.join(HERE, "ddz_oracle.c")
-    hdr = os.path.join(HERE, "ddz_oracle.h")
+    deps = [os.path.join(HERE, f) for f in ("ddz_oracle.c", "ddz_auto_oracle.c", "ddz_oracle.h", "Makefile")]
     stale = (not os.path.exists(so)) or any(
-        os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+        os.path.getmtime(p) > os.path.getmtime(so) for p in deps)
     if force or stale:
         subprocess.check_call(["make", "-C", HERE, name],
                               stdout=subprocess.DEVNULL)
@@ -82,6 +81,15 @@ def lib():
         L.ddzo_select.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, p, p, C.c_double, p]
         L.ddzo_rollout_random.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, p, p]
         L.ddzo_rollout_random.restype = C.c_int64
+        L.ddzo_cards_value_x2.argtypes = [p]
+        for f in (L.ddzo_combinations_recursive, L.ddzo_combinations_nosplit):
+            f.argtypes = [p, C.c_int, p, p, C.c_int64, p]
+            f.restype = C.c_int64
+        L.ddzo_auto_combinations.argtypes = [p, C.c_int, p, C.c_int64, p]
+        L.ddzo_auto_combinations.restype = C.c_int64
+        L.ddzo_auto_choose.argtypes = [p, p, p, C.c_int, p]
+        L.ddzo_auto_choose.restype = C.c_int
+        L.ddzo_env_auto_choose.argtypes = [p, C.c_int64, C.c_int, p, p]
         L.ddzo_init()
         _libs[_jk] = L
     return _libs[_jk]
@@ -158,7 +166,7 @@ class OracleEnv:
         reward = np.zeros(self.T, np.int8)
         illegal = np.zeros(self.T, np.uint8)
         traj = np.zeros((self.T, TR_BYTES), np.uint8) if want_traj else None
-        if mode == STEP_CHOICE:
+        if mode in (STEP_CHOICE, STEP_IDS):
             sel = np.ascontiguousarray(sel, np.int32)
         elif mode == STEP_ROWS:
             sel = np.ascontiguousarray(sel, np.int8)
@@ -178,6 +186,13 @@ class OracleEnv:
         lib().ddzo_select(_ptr(self.state), self.T, self.seed, self.gid_base, _ptr(q), _ptr(self.offsets),
                           float(epsilon), _ptr(out))
         return out
+
+    def auto_choose(self, auto_roles=0b101, want_stats=False):
+        """Env.step_auto's choice (RuleBasedModel.choose) per table: action id, -1 where the actor is not a rule agent."""
+        ids = np.zeros(self.T, np.int32)
+        st = np.zeros(2, np.int64)
+        lib().ddzo_env_auto_choose(_ptr(self.state), self.T, int(auto_roles), _ptr(ids), _ptr(st))
+        return (ids, st) if want_stats else ids
 
     def rollout_random(self, n_iters):
         sl = C.c_int64(0)
@@ -216,3 +231,64 @@ def rows_to_onehot(rows):
     out = np.zeros((r.shape[0], 15, 4), np.float32)
     lib().ddzo_rows_to_onehot(_ptr(r), r.shape[0], _ptr(out))
     return out
+
+
+# ---- rule-based opponent (oracle/ddz_auto_oracle.c) ----
+def cards_value():
+    """cards_value of rule_based/utils/evaluator.py:10-47 as float64[13527]."""
+    v = np.zeros(NUM_ACTIONS, np.int16)
+    lib().ddzo_cards_value_x2(_ptr(v))
+    return v.astype(np.float64) / 2.0
+
+
+def _unpack_combs(buf, used):
+    out, p = [], 0
+    while p < used:
+        n = int(buf[p])
+        out.append(buf[p + 1:p + 1 + n].tolist())
+        p += 1 + n
+    return out
+
+
+def _combinations(fn, mask, target, cap=1 << 22):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    target = np.ascontiguousarray(target, np.uint8)
+    buf = np.zeros(cap, np.int32)
+    nc = C.c_int64(0)
+    used = fn(_ptr(mask), mask.shape[0], _ptr(target), _ptr(buf), cap, C.byref(nc))
+    if used > cap:
+        buf = np.zeros(used, np.int32)
+        used = fn(_ptr(mask), mask.shape[0], _ptr(target), _ptr(buf), used, C.byref(nc))
+    return _unpack_combs(buf, used)
+
+
+def combinations_recursive(mask, target):
+    """stand-in for the absent native env.get_combinations_recursive (decomposer spec v1)."""
+    return _combinations(lib().ddzo_combinations_recursive, mask, target)
+
+
+def combinations_nosplit(mask, card_mask):
+    """stand-in for the absent native env.get_combinations_nosplit (decomposer spec v1)."""
+    return _combinations(lib().ddzo_combinations_nosplit, mask, card_mask)
+
+
+def auto_combinations(hand15, follow):
+    h = np.ascontiguousarray(hand15, np.int8)
+    cap = 1 << 22
+    buf = np.zeros(cap, np.int32)
+    nc = C.c_int64(0)
+    used = lib().ddzo_auto_combinations(_ptr(h), int(bool(follow)), _ptr(buf), cap, C.byref(nc))
+    assert used <= cap
+    return _unpack_combs(buf, used)
+
+
+def auto_choose(hand15, last15, left3, role, want_stats=False):
+    """RuleBasedModel.choose (rule_based_model.py:43-101) -> canonical action id."""
+    h = np.ascontiguousarray(hand15, np.int8)
+    l = None if last15 is None else np.ascontiguousarray(last15, np.int8)
+    lf = np.ascontiguousarray(left3, np.int32)
+    st = np.zeros(2, np.int64)
+    a = lib().ddzo_auto_choose(_ptr(h), _ptr(l), _ptr(lf), int(role), _ptr(st))
+    if a < 0:
+        raise ValueError("last is not a combo of the action space")
+    return (a, st) if want_stats else a
