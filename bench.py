@@ -2,17 +2,21 @@
 """Headline benchmark: env steps/s of the batched lock-step engine (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-A "step" is one lock-step iteration of the hot path over all tables of this rank:
-legal-move enumeration into the per-table list + random-policy action application with
-auto-reset (configs[1]: 4096 tables per MI355X, random policy, legal-move list only).
-Weak scaling: every GPU runs 4096 tables of the global id range and the timed region is the
-same at every N (tables are independent: no data-path collective).  For N > 1 the path's one
-exchange -- packed trajectories gathered to rank 0 over RCCL -- is measured right after the
-headline region and reported in config.exchange.  Rank 0 prints ONE JSON line.
+A "step" is one lock-step iteration of the hot path over all tables of this rank: legal-move enumeration into the
+per-table list + random-policy action application with auto-reset (game.py:169-181 with envi.py:79-116).
+  N = 1: BASELINE.json configs[1], 4096 tables on one MI355X, random policy, legal-move list only.
+  N > 1: 65,536 tables per GPU (configs[4] = 524,288 tables at N = 8), weak scaling: every GPU owns a range of the
+         global table ids and the timed region is the same at every N (tables are independent: no data-path
+         collective).  The path's one exchange -- packed trajectories gathered to rank 0 over RCCL -- is measured
+         right after the headline region (config.exchange, env_steps_per_s_with_gather).
+The K-iteration launch is repeated until at least 50 ms have been timed, whatever K is (a single short launch
+would measure launch latency); `value` and `ms_per_step` are means over all timed iterations.  Rank 0 prints ONE
+JSON line; at N = 1 it also carries short measured legs of the other single-GPU configs (`configs`).
 """
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -21,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MIN_TIMED_S = 0.05      # every timed region covers at least this much GPU time
 
 
 def cpu_baseline(tables, budget_s):
@@ -57,16 +62,125 @@ def cpu_baseline(tables, budget_s):
                       "13,527-row scan per state"}
 
 
+def timed_loop(fn, sync, min_s=MIN_TIMED_S, max_reps=1 << 16):
+    """Call fn() repeatedly between two syncs until >= min_s have been timed; returns (seconds, calls)."""
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    fn()
+    sync()
+    est = max(time.perf_counter() - t0, 1e-6)
+    reps = int(min(max_reps, max(1, math.ceil(min_s / est))))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return time.perf_counter() - t0, reps
+
+
+def other_config_legs(pkg, torch, dev):
+    """Short measured legs of the other single-GPU configurations of BASELINE.json (numbers, not prose)."""
+    out = {}
+    T = 65536
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    env = pkg.BatchedEnv(T, seed=0, device=dev)
+    env.reset()
+    env.rollout_random(200)
+    # (1) the random-policy rollout of the headline at 65,536 tables
+    k = 500
+    dt, reps = timed_loop(lambda: env.rollout_random(k), sync)
+    out["tables_65536_random_rollout"] = {"env_steps_per_s": T * k * reps / dt, "iterations": k * reps,
+                                          "us_per_iteration": dt / (k * reps) * 1e6}
+    # (2) configs[2]'s environment side: the loop a policy drives through the slab API -- face, selection over
+    # per-action values, apply + next lists; one launch each (game.py:95-104, dqn.py:50-71).  The Q values are random
+    # numbers standing in for the network's output (the network itself is out of scope: SURVEY 2 #8).
+    env.legal_slab()
+    face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=dev)
+    q = torch.rand((T, env.slab_stride), dtype=torch.float32, device=dev)
+    choice = torch.empty(T, dtype=torch.int32, device=dev)
+
+    def policy_iter():
+        env.observe(3, out=face)
+        env.select_slab(q, out=choice)
+        env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+
+    dt, reps = timed_loop(lambda: [policy_iter() for _ in range(20)], sync)
+    out["tables_65536_policy_loop_slab"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
+                                            "us_per_iteration": dt / (20 * reps) * 1e6,
+                                            "loop": "observe(EnvCooperationSimplify) + select_slab(random q) + step_slab(CHOICE)"}
+    dt, reps = timed_loop(lambda: [env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True) for _ in range(20)], sync)
+    out["tables_65536_step_slab_only"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6}
+    # (3) configs[3]: farmers played by the rule-based opponent (Env.step_auto), the lord by the random policy
+    def auto_iter():
+        ids = env.auto_choose(0b101)
+        env.step_slab(ids, pkg.STEP_IDS, auto_reset=True)
+
+    env.reset()           # whole episodes against the rule agent: start from fresh deals and play past the first
+    env.legal_slab()      # games (a rule-agent game lasts ~25 plies) before episodes are counted
+    for _ in range(40):
+        auto_iter()
+    s0 = env.stats()
+    dt, reps = timed_loop(lambda: [auto_iter() for _ in range(5)], sync, min_s=0.2, max_reps=40)
+    s1 = env.stats()
+    eps = max(1, s1["episodes"] - s0["episodes"])
+    lord, farm = s1["lord_wins"] - s0["lord_wins"], (s1["up_wins"] - s0["up_wins"]) + (s1["down_wins"] - s0["down_wins"])
+    out["tables_65536_rule_opponent"] = {
+        "env_steps_per_s": T * 5 * reps / dt, "us_per_iteration": dt / (5 * reps) * 1e6,
+        "mean_episode_return": {"lord": 100.0 * (lord - farm) / eps, "up": 50.0 * (farm - lord) / eps,
+                                "down": 50.0 * (farm - lord) / eps},
+        "episodes": eps, "loop": "auto_choose(farmers) + step_slab(IDS), lord = engine RNG; reward_dict of game.py:13-14"}
+    assert env.status() == 0
+    del env, q, face
+    return out
+
+
+def issue_roofline(steps_timed, dur_launch):
+    """The bound this integer path really runs into: vector-ALU issue.  Instructions per env step and the clock come
+    from the committed PMC passes (profiles/pmc_traffic.json), the cost of an instruction from the measured table of
+    tools/valu_issue_probe.hip (profiles/r02_valu_issue_probe.json), the rate is live."""
+    try:
+        prof = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("k_rollout", {})
+        v = prof["valu"]
+        probe = json.load(open(os.path.join(REPO, "profiles", "r02_valu_issue_probe.json")))
+    except Exception:
+        return None
+    cyc = {}
+    for r in probe["rows"]:
+        if r["waves_per_simd"] == 4:  # k_rollout runs four waves per SIMD at 4096 tables
+            cyc[r["kind"]] = r["cycles_per_instr_per_simd"]
+    full = (cyc["v_add_u32"] + cyc["v_and_b32/v_or_b32"]) / 2            # plain 32-bit VALU
+    half = (cyc["v_lshlrev_b64"] + cyc["v_add_co_u32+v_addc_co_u32"] + cyc["v_sub_co_u32+v_subb_co_u32"]
+            + cyc["v_mul_lo_u32"] + cyc["v_mbcnt_lo+v_mbcnt_hi"]) / 5   # 64-bit shifts, carry chains, mul, mbcnt
+    mix = prof.get("valu_mix")  # measured share of the slow classes (profiles, SQ_INSTS_VALU_INT64 ...), if collected
+    share_half = mix["share_half_rate"] if mix else 0.5
+    cpi = (1 - share_half) * full + share_half * half
+    simds = 256 * 4
+    peak = simds * v["clock_GHz"] * 1e9 / cpi
+    ach = v["SQ_INSTS_VALU_per_env_step"] * steps_timed / dur_launch
+    return {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
+            "valu_insts_per_env_step": v["SQ_INSTS_VALU_per_env_step"], "cycles_per_instr_full_rate": full,
+            "cycles_per_instr_half_rate": half, "share_half_rate": share_half,
+            "share_source": "measured (profiles/pmc_traffic.json valu_mix)" if mix else "assumed 0.5",
+            "peak_if_all_full_rate": simds * v["clock_GHz"] / full, "peak_if_all_half_rate": simds * v["clock_GHz"] / half,
+            "note": "cycles per wave64 instruction per SIMD measured by tools/valu_issue_probe.hip at 4 waves/SIMD "
+                    "(profiles/r02_valu_issue_probe.json): ~2.4 for plain 32-bit ops (the guide's 2-cycle SIMD-32 figure), "
+                    "~4.5 for 64-bit shifts / carry chains / v_mul_lo / v_mbcnt, which the nibble-SWAR code is made of"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--tables", type=int, default=4096, help="tables per GPU (configs[1])")
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--tables", type=int, default=0,
+                    help="tables per GPU; default 4096 at N = 1 (configs[1]), 65536 at N > 1 (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--exchange-steps", type=int, default=500, help="N > 1: iterations of the trajectory-gather leg")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the short legs of the other configs")
+    ap.add_argument("--exchange-steps", type=int, default=200, help="N > 1: iterations of the trajectory-gather leg")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the trajectory-gather leg")
+    ap.add_argument("--strict-exchange", action="store_true", help="N > 1: a failing gather leg is a non-zero exit")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE GPU (all ranks on cuda:0, gloo, host-staged gather): control-flow rehearsal only")
     a = ap.parse_args()
@@ -90,7 +204,7 @@ def main():
             import datetime
             dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
 
-    T = a.tables
+    T = a.tables if a.tables > 0 else (4096 if world == 1 else 65536)
     total_tables = T * world
     _, base = ddist.shard_tables(total_tables, rank, world)
     env = pkg.BatchedEnv(T, seed=0, device=dev, table_id_base=base, want_ids=False)
@@ -102,13 +216,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # The timed region is the same at every N: K lock-step iterations of this rank's 4096 tables.  Tables
-    # are independent, so there is no data-path collective while stepping (weak scaling).
+    # ---- headline: the K-iteration launch, repeated until >= 50 ms are timed (same repeat count on every rank)
     env.rollout_random(W)
-    s0 = env.stats()  # cumulative counters so far (sync)
     barrier()
     t0 = time.perf_counter()
     env.rollout_random(K)
+    torch.cuda.synchronize(dev)
+    est = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(est, op=dist.ReduceOp.MIN)
+    R = int(min(1 << 16, max(1, math.ceil(MIN_TIMED_S / max(float(est.item()), 1e-6)))))
+    s0 = env.stats()  # cumulative counters so far (sync)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(R):
+        env.rollout_random(K)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -118,15 +240,15 @@ def main():
     s1 = env.stats()
     st = {k: s1[k] - s0[k] for k in s1}
     status = env.status()
-    assert st["plies"] == T * K and status == 0, (st, status)
+    assert st["plies"] == T * K * R and status == 0, (st, status)
 
-    # The path's one exchange, measured beside the headline, never inside it: every ply also
-    # writes its 32-byte trajectory record and the batch goes to the learner (rank 0) over RCCL in two
-    # half-batches; the gather of the first half overlaps the rollout of the second one.
+    # ---- the path's one exchange, measured beside the headline, never inside it: every ply also writes
+    # its 32-byte trajectory record and the batch goes to the learner (rank 0) over RCCL in two half-batches; the
+    # gather of the first half overlaps the rollout of the second one.
     exchange = None
     if world > 1 and not a.no_exchange:
         try:
-            KX = max(2, min(K, a.exchange_steps))
+            KX = max(2, a.exchange_steps)
             half = KX // 2
             shard = [T] * world
             stage = (lambda x: x.cpu()) if a.rehearse else (lambda x: x)
@@ -150,89 +272,100 @@ def main():
             tmx = torch.tensor([dtx], dtype=torch.float64, device=dev)
             dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
             dtx = float(tmx.item())
+            digest = None
             if rank == 0:
                 assert ga.shape == (half, total_tables, pkg.TRAJ_PACKED_BYTES) and gb.shape == (KX - half, total_tables, pkg.TRAJ_PACKED_BYTES)
                 rec = ddist.unpack_trajectory(gb[-1].to(dev))
-                assert int(rec["ply"].max()) < 200 and int(rec["role"].max()) <= 2 and int(rec["id"].max()) < 13527
-            exchange = {"steps": KX, "env_steps_per_s_with_gather": total_tables * KX / dtx,
-                        "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_PACKED_BYTES, "seconds": dtx,
+                assert int(rec["ply"].max()) < 200 and int(rec["role"].max()) <= 2
+                assert int(rec["id"][rec["flags"] == 0].max()) < 13527
+                x = torch.cat([ga, gb]).to(dev).contiguous().view(torch.int64).view(-1)
+                # digest of every gathered record in (iteration, global table) order: the rehearsal test recomputes it
+                # from a single-process rollout of the union of the shards
+                digest = int((x * 31 + (x >> 13) + torch.arange(x.numel(), device=dev) * x).sum().item())
+            exchange = {"steps": KX, "iterations_before": W + K * (R + 1), "env_steps_per_s_with_gather": total_tables * KX / dtx,
+                        "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_PACKED_BYTES, "seconds": dtx, "digest": digest,
                         "note": "trajectory records (32 B per ply per table) written, packed to 8 B and gathered to rank 0, pipelined "
                                 "in two half-batches; measured after the headline region"}
             del traj_a, traj_b, ga, gb
-            s1 = env.stats()
-        except Exception as ex:  # the headline above stands on its own; report, do not lose the line
+        except Exception as ex:  # the headline above stands on its own; report loudly, do not lose the line
             exchange = {"error": repr(ex)[:300]}
-            s1 = env.stats()
+            print(f"[bench] rank {rank}: trajectory-gather leg FAILED: {ex!r}", file=sys.stderr, flush=True)
     mean_a = st["legal_rows"] / max(1, st["plies"])
 
-    # duration of the dominant kernel: all iterations run inside ONE k_rollout launch; two HIP
-    # events around that launch on the launching stream (same workload, K iterations)
-    n_timed = K
-    ms_launch = env.rollout_random_timed(n_timed)
-    s2 = env.stats()
-    steps_timed = s2["plies"] - s1["plies"]
-    mean_a2 = (s2["legal_rows"] - s1["legal_rows"]) / max(1, steps_timed)
-    # algorithmic bytes per env step, SURVEY.md 8(d): 128 state read + 128 state write + 4 list
-    # size/offset + 16*A legal rows (DESIGN.md 3 states what the kernel really moves)
+    # ---- duration of the dominant kernel: all K iterations run inside ONE k_rollout launch; two HIP events around
+    # every launch on the launching stream, repeated until >= 50 ms of kernel time are summed
+    sa = env.stats()
+    ms_total, n_launch = 0.0, 0
+    while ms_total < MIN_TIMED_S * 1e3 and n_launch < (1 << 16):
+        ms_total += env.rollout_random_timed(K)
+        n_launch += 1
+    sb = env.stats()
+    steps_timed = sb["plies"] - sa["plies"]
+    mean_a2 = (sb["legal_rows"] - sa["legal_rows"]) / max(1, steps_timed)
+    # algorithmic bytes per env step, SURVEY.md 8(d): 128 state read + 128 state write + 4 list size/offset + 16*A
+    # legal rows (DESIGN.md 3 states what the kernel really moves)
     b_step = 260 + 16 * mean_a2
-    b_launch = b_step * steps_timed
-    dur_launch = ms_launch * 1e-3
+    dur_launch = ms_total * 1e-3 / n_launch           # mean duration of one K-iteration launch
+    steps_per_launch = steps_timed / n_launch
+    b_launch = b_step * steps_per_launch
     dominant = "k_rollout"
     ach = b_launch / dur_launch / 1e9
     traffic = None
-    issue = None
-    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            prof = json.load(open(tfile)).get(dominant, {})
-            per_step = prof.get("hbm_bytes_per_env_step")
-            traffic = per_step * steps_timed if per_step is not None else None
-            # the bound this integer path really runs into: vector-ALU issue slots.  Instructions
-            # per env step and the clock come from the committed PMC pass, the rate is live
-            v = prof.get("valu")
-            if v:
-                peak = 256 * 4 * v["clock_GHz"] * 1e9 / 4  # wave-instructions/s, 4 cycles each per SIMD16
-                ach_i = v["SQ_INSTS_VALU_per_env_step"] * steps_timed / dur_launch
-                issue = {"bound": "valu-issue", "achieved": ach_i / 1e9, "peak": peak / 1e9,
-                         "unit": "G wave-instr/s", "frac": ach_i / peak,
-                         "valu_insts_per_env_step": v["SQ_INSTS_VALU_per_env_step"]}
-        except Exception:
-            traffic = None
+    try:
+        prof = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dominant, {})
+        per_step = prof.get("hbm_bytes_per_env_step")
+        traffic = per_step * steps_per_launch if per_step is not None else None
+    except Exception:
+        traffic = None
+    issue = issue_roofline(steps_per_launch, dur_launch)
 
-    # the same loop with packed CSR lists (one launch per iteration): reported, not the headline
-    n_csr = min(K, 500)
+    # ---- the same loop with packed CSR lists (one launch per iteration): a number, not the headline
     env.rollout_random_csr(20)
     torch.cuda.synchronize(dev)
-    tc = time.perf_counter()
-    env.rollout_random_csr(n_csr)
-    torch.cuda.synchronize(dev)
-    csr_rate = T * n_csr / (time.perf_counter() - tc)
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(50), lambda: torch.cuda.synchronize(dev))
+    csr_rate = T * 50 * repc / dtc
 
     if rank == 0:
         out = {
-            "metric": "env steps/sec (batched tables)", "value": total_tables * K / dt,
+            "metric": "env steps/sec (batched tables)", "value": total_tables * K * R / dt,
             "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / (K * R) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list "
-                                   "only (no NN), auto-reset; BASELINE.json configs[1]",
+            "timed_steps": K * R, "repeats_of_the_steps_launch": R, "timed_seconds": dt,
+            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list only (no NN), "
+                                   f"auto-reset; BASELINE.json {'configs[1]' if world == 1 else 'configs[4] (65,536 tables per GPU)'}",
                        "tables_per_gpu": T, "total_tables": total_tables,
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
-                       "list_layout": "slab (fixed-stride segment per table); packed-CSR variant of the "
-                                      "same loop: %.4g env steps/s per GPU" % csr_rate,
+                       "list_layout": "slab (fixed-stride segment per table)",
+                       "csr_env_steps_per_s": csr_rate,
                        "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
-                         "launch_us": dur_launch * 1e6, "env_steps_per_launch": steps_timed,
-                         "us_per_iteration": dur_launch * 1e6 / n_timed,
+                         "launch_us": dur_launch * 1e6, "launches_timed": n_launch, "env_steps_per_launch": steps_per_launch,
+                         "us_per_iteration": dur_launch * 1e6 / K,
                          "algorithmic_bytes_per_env_step": b_step,
-                         "algorithmic_bytes_per_launch": b_launch, "issue": issue},
+                         "algorithmic_bytes_per_launch": b_launch,
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / launch time: a store rate into the write-back "
+                                 "L2, not HBM utilisation -- every iteration overwrites the same state rows / list slab, so "
+                                 "the HBM counters (traffic) see ~2 B per env step.  The path is instruction-issue bound: "
+                                 "see issue",
+                         "issue": issue},
         }
+        if exchange and "env_steps_per_s_with_gather" in exchange:
+            out["env_steps_per_s_with_gather"] = exchange["env_steps_per_s_with_gather"]
+        if world == 1 and not a.no_configs:
+            try:
+                out["configs"] = other_config_legs(pkg, torch, dev)
+            except Exception as ex:
+                out["configs"] = {"error": repr(ex)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)
         print(json.dumps(out), flush=True)
+    failed = bool(exchange and "error" in exchange)
     if world > 1:
         dist.destroy_process_group()
+    if failed and a.strict_exchange:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/ddz_env.h"
 #include "ddz_device.h"
 
@@ -117,7 +120,7 @@ constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS stagin
 constexpr int EM_MASK = 4;    // bit `id` of the wave's LDS mask (get_mask, utils.py:45-63)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
-constexpr int STAGE_CAP = DDZ_NATIVE_JOKER_KICKERS ? 512 : 500;  // >= the largest list of a <=20-card hand (497, tests/test_rules_bounds.py);
+constexpr int STAGE_CAP = DDZ_NATIVE_JOKER_KICKERS ? 512 : 500;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
                                  // 500 keeps k_rollout's block at 53 KB of LDS = three blocks per CU
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
@@ -555,6 +558,17 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   constexpr bool SLAB = (FLAGS & F_SLAB) != 0;
   constexpr bool COUNT = !SLAB && (FLAGS & (F_STEP | F_RESET | F_COUNT)) != 0;
   constexpr bool PICK = ENUM && STEP && MODE == DDZ_STEP_RANDOM;
+#ifdef DDZ_STAMP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define TACC(k)                                                      \
+  do {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    tacc[k] += now_ - tlast;                                         \
+    tlast = now_;                                                    \
+  } while (0)
+#else
+#define TACC(k) do { } while (0)
+#endif
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * a.tpw;
@@ -586,8 +600,10 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       if (pre_idx >= 0) pre_row = a.rows[(t0 + lane) * a.stride + pre_idx];
     }
   }
+  TACC(0);  // prologue loads issued
   hot_fill<TB>(hot);
   __syncthreads();
+  TACC(1);  // hot fill + barrier
   if (ENUM && ntab > 0) base = (int64_t)wave_sum(part) + loc0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     uint32_t qinfo = mk_info(EMPTY, 0, 1);
     int cnt = 0;
     Pick pk{-1, 0, 0, 0, 0};
+    TACC(2);  // decode
     if (ENUM) {
       cnt = (int)rl((uint32_t)cnt_l, i);
       if (lane == 0) a.offsets[t] = (int32_t)base;
@@ -747,6 +764,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         qhand = h1; qinfo = mk_info(EMPTY, 0, 1);
       }
     }
+    TACC(3);  // select + apply + outputs
     if (changed) {
       if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
       if (COUNT || SLAB) {                     // query of the new actor
@@ -772,8 +790,15 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       if (lane == 0) a.slab_counts[t] = n;
       slab_rows += n;
     }
+    TACC(4);  // state store + list of the new state
     base += cnt;
   }
+#ifdef DDZ_STAMP
+  if (g_stamps && lane == 0 && ntab > 0 && SLAB && STEP) {
+    tacc[5] = ntab;
+    for (int q = 0; q < 8; ++q) g_stamps[16 * t0 + q] = tacc[q];
+  }
+#endif
   if (ENUM && ntab > 0 && t0 + ntab == a.T && lane == 0) {
     a.offsets[a.T] = (int32_t)base;
     *a.legal_rows += base;
@@ -1330,6 +1355,26 @@ __global__ __launch_bounds__(BLOCK) void k_observe(const uint8_t* __restrict__ s
   store_stream(&out[idx], v);
 }
 
+// get_state_prob_manual(known60, size1, size2) (server/core.py:26-33; native in the reference, prob planes spec v1):
+// one thread per (query, rank); known = thermometer u8 [n][60] of own cards + cards played, decoded by its row sum
+// (onehot2arr, envi.py:148-157); out f32 [n][2][15][4] -- the same expression k_observe evaluates for its two planes.
+__global__ __launch_bounds__(BLOCK) void k_state_prob(const uint8_t* __restrict__ known60, const int32_t* __restrict__ sizes,
+                                                      int64_t n, float4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (idx >= n * 15) return;
+  const int64_t q = idx / 15;
+  const int i = (int)(idx - q * 15);
+  const uchar4 k4 = *(const uchar4*)(known60 + q * 60 + 4 * i);
+  const int known = (k4.x != 0) + (k4.y != 0) + (k4.z != 0) + (k4.w != 0), total = i < 13 ? 4 : 1;
+  const int n1 = sizes[2 * q], n2 = sizes[2 * q + 1];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float fr = n1 + n2 > 0 ? (float)(p == 0 ? n1 : n2) / (float)(n1 + n2) : 0.f;
+    auto slot = [&](int j) { return (j >= known && j < total) ? fr : 0.f; };
+    out[(q * 2 + p) * 15 + i] = make_float4(slot(0), slot(1), slot(2), slot(3));
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_onehot(const uint8_t* __restrict__ rows, int64_t n,
                                                   float4* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1360,7 +1405,9 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(const uint4* __restrict__ t
   if (i >= n) return;
   const uint4 row = traj[2 * i], m = traj[2 * i + 1];
   const uint64_t nib = pack_row(row);
-  int lo = 0, hi = NUM_ACTIONS_X - 1, id = 0x3FFF;  // 0x3FFF: not a row of the action space
+  // 0x3FFF: not an action -- a row outside the action space, or a record of a frozen table / an illegal selection
+  // (flags != 0: its all-zero row is NOT the pass)
+  int lo = 0, hi = ((m.x >> 24) & 3) ? -1 : NUM_ACTIONS_X - 1, id = 0x3FFF;
   while (lo <= hi) {
     const int mid = (lo + hi) >> 1;
     const uint64_t v = g_sorted_nib[mid];
@@ -1435,10 +1482,23 @@ int launch_moves(const Scratch& sc, const int8_t* hands, const int8_t* lasts, in
 // the record table is built once per device, on the null stream, the first time a handle
 // (or a stateless call) needs it; this is the only place the library synchronises by itself
 constexpr int MAX_DEVICES = 64;
-bool g_table_ready[MAX_DEVICES] = {};
+// The stateless entry points (ddz_get_moves, ddz_action_table, ddz_pack_trajectory, ddz_auto_choose) carry no handle,
+// so two host threads may make the first call together: one mutex per device serialises the build, the flag is
+// read with acquire / written with release so that a reader never sees a half-built table.
+std::mutex g_table_mutex[MAX_DEVICES];
+std::atomic<bool> g_table_ready[MAX_DEVICES];
+int build_table_locked(int device);
 int ensure_table(int device) {
   if (device < 0 || device >= MAX_DEVICES) return DDZ_ENODEV;
-  if (g_table_ready[device]) return DDZ_OK;
+  if (g_table_ready[device].load(std::memory_order_acquire)) return DDZ_OK;
+  std::lock_guard<std::mutex> lock(g_table_mutex[device]);
+  if (g_table_ready[device].load(std::memory_order_relaxed)) return DDZ_OK;
+  const int rc = build_table_locked(device);
+  if (rc == DDZ_OK) g_table_ready[device].store(true, std::memory_order_release);
+  return rc;
+}
+int build_table_locked(int device) {
+  (void)device;
   int32_t* flag = nullptr;
   hipError_t r = hipHostMalloc((void**)&flag, sizeof(int32_t), 0);  // host-pinned status word
   if (r != hipSuccess) return hip_fail(r);
@@ -1476,7 +1536,6 @@ int ensure_table(int device) {
     }
     free(recs); free(tab); free(nibs); free(ids);
   }
-  if (rc == DDZ_OK) g_table_ready[device] = true;
   return rc;
 }
 
@@ -1665,7 +1724,7 @@ int ddz_step(ddz_env_t* e, int mode, const void* sel, const int32_t* offsets, co
 int ddz_legal_slab(ddz_env_t* e, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4)) return DDZ_EINVAL;
-  if (!counts || !rows || stride <= 0) return DDZ_EINVAL;
+  if (!counts || !rows || stride < DDZ_SLAB_MIN_STRIDE) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   Io io;
@@ -1677,7 +1736,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
                   int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || (mode == DDZ_STEP_ROWS ? !al(sel, 16) : !al(sel, 4))) return DDZ_EINVAL;
-  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_IDS || !counts || !rows || stride <= 0) return DDZ_EINVAL;
+  if (mode < DDZ_STEP_RANDOM || mode > DDZ_STEP_IDS || !counts || !rows || stride < DDZ_SLAB_MIN_STRIDE) return DDZ_EINVAL;
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1737,6 +1796,18 @@ int ddz_rows_to_onehot(int device, const int8_t* rows, int64_t n, float* out, vo
   return check_launch();
 }
 
+int ddz_state_prob(int device, const uint8_t* known60, const int32_t* sizes, int64_t n, float* out, void* stream) {
+  if (!al(known60, 4) || !al(sizes, 4) || !al(out, 16)) return DDZ_EINVAL;
+  if (n < 0 || (n > 0 && (!known60 || !sizes || !out))) return DDZ_EINVAL;
+  if (n == 0) return DDZ_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  const int64_t m = n * 15;
+  hipLaunchKernelGGL(k_state_prob, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     known60, sizes, n, (float4*)out);
+  return check_launch();
+}
+
 int ddz_get_moves(int device, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* offsets, int8_t* rows,
                   int32_t* ids, int64_t cap, void* scratch, int64_t scratch_bytes, void* stream) {
   if (!al(hands, 16) || !al(lasts, 16) || !al(rows, 16) || !al(offsets, 4) || !al(ids, 4) || !al(scratch, 16)) return DDZ_EINVAL;
@@ -1787,7 +1858,7 @@ int ddz_rollout_random(ddz_env_t* e, int64_t n_iters, int32_t* counts, int8_t* r
                        int64_t* stats, uint8_t* traj, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || !al(stats, 8)) return DDZ_EINVAL;
-  if (n_iters < 0 || !counts || !rows || stride < 1) return DDZ_EINVAL;
+  if (n_iters < 0 || !counts || !rows || stride < DDZ_SLAB_MIN_STRIDE) return DDZ_EINVAL;
   if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
@@ -1829,7 +1900,7 @@ int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int
                              int64_t stride, double* ms, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4)) return DDZ_EINVAL;
-  if (n_iters <= 0 || !counts || !rows || stride < 1 || !ms) return DDZ_EINVAL;
+  if (n_iters <= 0 || !counts || !rows || stride < DDZ_SLAB_MIN_STRIDE || !ms) return DDZ_EINVAL;
   if (e->T * stride > 0x7FFFFFFF) return DDZ_ECAP;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;

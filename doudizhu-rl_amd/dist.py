@@ -108,8 +108,10 @@ def unpack_trajectory(traj, action_rows=None):
                "reward": torch.where(rc == 2, -torch.ones_like(rc), rc), "flags": (w0 >> 28) & 3,
                "choice": (w1 & 0x3FF) - 1, "ply": (w1 >> 10) & 0xFF, "episode": (w1 >> 18) & 0x3FFF}
         if action_rows is not None:
-            ids = out["id"].clamp(max=action_rows.shape[0] - 1).to(action_rows.device)
-            out["row"] = action_rows[ids]
+            ids = out["id"].to(action_rows.device)
+            none = ids >= action_rows.shape[0]                      # 0x3FFF: the record holds no action -> zero row
+            out["row"] = torch.where(none.unsqueeze(-1), torch.zeros_like(action_rows[:1]),
+                                     action_rows[ids.clamp(max=action_rows.shape[0] - 1)])
         return out
     t = traj.to(torch.int64)
     u16 = lambda lo: t[..., lo] | (t[..., lo + 1] << 8)  # noqa: E731

@@ -368,6 +368,23 @@ def rows_to_onehot(rows):
     return out
 
 
+def state_prob(known60, size1, size2, device="cuda:0"):
+    """get_state_prob_manual(known60, size1, size2) (server/core.py:26-33) for a batch: known60 [n,60] thermometers
+    of own cards + cards played, size1 / size2 [n] = cards left of the next / next-but-one player.  Returns f32
+    [n,2,15,4] on the device (prob planes spec v1: the last two planes of `face`)."""
+    L = _lib.lib()
+    dev = _require_gpu(device)
+    k = torch.as_tensor(known60).reshape(-1, 60)
+    k = (k != 0).to(device=dev, dtype=torch.uint8).contiguous()
+    n = k.shape[0]
+    sizes = torch.stack([torch.as_tensor(size1).reshape(n), torch.as_tensor(size2).reshape(n)], 1)
+    sizes = sizes.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty((n, 2, 15, 4), dtype=torch.float32, device=dev)
+    if n:
+        check(L.ddz_state_prob(dev.index, _p(k), _p(sizes), n, _p(out), _stream(dev)))
+    return out
+
+
 def action_table(device="cuda:0", native_joker_kickers=False):
     """The canonical action table on the device: int8 [n_actions, 16] = counts[15] + category, action id =
     row index (the order of card.py:34-159 get_action_space(); + the 24 joker-kicker rows if asked for)."""

@@ -17,7 +17,7 @@ import torch
 
 from . import config as conf
 from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE, STEP_IDS,
-                     rows_to_onehot)
+                     rows_to_onehot, state_prob)
 
 
 class Env:
@@ -70,6 +70,16 @@ class Env:
         prev = self.arr2cards(self.recent_handout[(role + 2) % 3].astype(int))
         prevprev = self.arr2cards(self.recent_handout[(role + 1) % 3].astype(int))
         return [list(prev), list(prevprev)]
+
+    def get_state_prob(self):
+        """native get_state_prob() (envi.py:94): 120 floats, reshaped (2,15,4) by `face` -- prob planes spec v1."""
+        return self._b.observe(0)[0, 2:4].reshape(120).cpu().numpy()
+
+    def get_state_prob_manual(self, known60, size1, size2):
+        """native get_state_prob_manual (server/core.py:26-33): the same planes from an explicit view of the game:
+        known60 = flattened thermometer of own cards + cards played, size1 / size2 = cards left of the next two players."""
+        return state_prob(np.asarray(known60).reshape(1, 60), [int(size1)], [int(size2)],
+                          device=self.device)[0].reshape(120).cpu().numpy()
 
     # ---- stepping ----
     def _apply(self, idx):

@@ -32,6 +32,9 @@ extern "C" {
 #define DDZ_ROW 16            /* packed row: int8 counts[15] (3..K,A,2,BJ,CJ; envi.py:122-124) + 1 aux byte */
 #define DDZ_NFIELDS 11
 #define DDZ_TRAJ_BYTES 32
+/* slab list layout: rows per table.  497 = the largest legal list of any hand of <= 20 cards, proven by exhaustive
+ * enumeration (tools/max_legal_bound.c; 521 with the joker-kicker rule set); smaller strides are DDZ_EINVAL. */
+#define DDZ_SLAB_MIN_STRIDE 512
 
 /* error codes */
 #define DDZ_OK 0
@@ -133,6 +136,13 @@ int ddz_step_slab(ddz_env_t* env, int mode, const void* sel, int32_t* counts, in
 /* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
 int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
 
+/* Replaces the native get_state_prob_manual(known60, size1, size2) (server/core.py:26-33; Env.get_state_prob(),
+ * envi.py:94, is the same function of the live table): known60 u8[n][60] = thermometer of the cards the actor can see
+ * (own hand + everything played), sizes int32[n][2] = cards left of the next and the next-but-one player;
+ * out f32[n][2][15][4] = the two probability planes of `face` (prob planes spec v1, DESIGN.md 4: PARITY UNPINNED,
+ * bit-identical to the last two planes ddz_observe writes for the same table).                                  */
+int ddz_state_prob(int device_id, const uint8_t* known60, const int32_t* sizes, int64_t n, float* out, void* stream);
+
 /* Replaces batch_arr2onehot (envi.py:139-146) on device: rows int8[n][16] -> f32 [n][15][4] */
 int ddz_rows_to_onehot(int device_id, const int8_t* rows, int64_t n, float* out, void* stream);
 
@@ -197,7 +207,7 @@ int ddz_select_slab(ddz_env_t* env, const float* q, const int32_t* counts, int64
 int ddz_action_table(int device_id, int8_t* rows, void* stream);
 
 /* 32-byte trajectory records -> 8-byte records (for the end-of-batch gather over xGMI: 4x fewer bytes).
- *   word 0: action id (14 bits; 0x3FFF = not an action) | n_legal << 14 (9 bits) | role << 23 (2) | done << 25 |
+ *   word 0: action id (14 bits; 0x3FFF = not an action: flags != 0, or a row outside the action space) | n_legal << 14 (9 bits) | role << 23 (2) | done << 25 |
  *           reward code << 26 (0: 0, 1: +1, 2: -1) | flags << 28 (bit0 illegal, bit1 frozen)
  *   word 1: choice + 1 (10 bits) | ply << 10 (8 bits) | episode << 18 (low 14 bits)
  * traj: u8[n][32], packed: u8[n][8], device memory. */

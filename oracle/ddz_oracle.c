@@ -502,6 +502,22 @@ void ddzo_env_observe(const uint8_t* s, int64_t T, int variant, float* out) {
   }
 }
 
+/* get_state_prob_manual(known60, size1, size2) (server/core.py:26-33), prob planes spec v1: the two planes of
+ * ddzo_env_observe from an explicit thermometer of the seen cards; out f32[2][15][4].                       */
+void ddzo_state_prob(const uint8_t* known60, int n1, int n2, float* out) {
+  float f1 = n1 + n2 > 0 ? (float)n1 / (float)(n1 + n2) : 0.0f;
+  float f2 = n1 + n2 > 0 ? (float)n2 / (float)(n1 + n2) : 0.0f;
+  for (int i = 0; i < NR; ++i) {
+    int known = 0, total = i < 13 ? 4 : 1;
+    for (int j = 0; j < 4; ++j) known += known60[i * 4 + j] != 0; /* onehot2arr: row sum (envi.py:148-157) */
+    for (int j = 0; j < 4; ++j) {
+      int unseen = j >= known && j < total;
+      out[i * 4 + j] = unseen ? f1 : 0.0f;
+      out[60 + i * 4 + j] = unseen ? f2 : 0.0f;
+    }
+  }
+}
+
 /* DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71): first index of the maximum;
  * exploration by the engine RNG, domain 3 (spec v1): draw.x < floor(eps * 2^32) -> uniform */
 void ddzo_select(const uint8_t* s, int64_t T, uint64_t seed, uint64_t gid_base, const float* q,

@@ -78,6 +78,7 @@ def lib():
         L.ddzo_planes.restype = C.c_int
         L.ddzo_env_observe.argtypes = [p, C.c_int64, C.c_int, p]
         L.ddzo_rows_to_onehot.argtypes = [p, C.c_int64, p]
+        L.ddzo_state_prob.argtypes = [p, C.c_int, C.c_int, p]
         L.ddzo_select.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, p, p, C.c_double, p]
         L.ddzo_rollout_random.argtypes = [p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, p, p]
         L.ddzo_rollout_random.restype = C.c_int64
@@ -292,3 +293,11 @@ def auto_choose(hand15, last15, left3, role, want_stats=False):
     if a < 0:
         raise ValueError("last is not a combo of the action space")
     return (a, st) if want_stats else a
+
+
+def state_prob(known60, n1, n2):
+    """get_state_prob_manual (server/core.py:26-33), prob planes spec v1: f32 [2,15,4]."""
+    k = np.ascontiguousarray(np.asarray(known60).reshape(60) != 0, np.uint8)
+    out = np.zeros((2, 15, 4), np.float32)
+    lib().ddzo_state_prob(_ptr(k), int(n1), int(n2), _ptr(out))
+    return out

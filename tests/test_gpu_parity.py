@@ -783,7 +783,9 @@ def test_action_table_and_compact_trajectory(pkg, golden):
     assert torch.equal(full["episode"] & 0x3FFF, comp["episode"])
     assert torch.equal(comp["row"][..., :15], full["row"][..., :15])
     played = (full["flags"] == 0)
-    assert int((comp["id"] == 0x3FFF).sum()) == 0 and bool(played.any()) and bool((full["flags"] & 2).any())
+    # a flagged record (frozen table / illegal selection) holds no action: id 0x3FFF, never 0 = the pass (include/ddz_env.h)
+    assert torch.equal(comp["id"] == 0x3FFF, ~played) and bool(played.any()) and bool((full["flags"] & 2).any())
+    assert int((comp["id"][played] == 0).sum()) > 0   # real passes keep id 0
     assert torch.equal(comp["row"][..., 15][played], full["row"][..., 15][played])
     # single-process gather (world 1): compact=True returns the packed form
     g = ddist.gather_trajectories(traj, compact=True)
@@ -830,5 +832,56 @@ def test_bench_contract():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
     assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 4096 * 300
     assert "workload" in j["config"] and "model" not in j["config"]
+    # self-sufficient timing: the 300-iteration launch is repeated until >= 50 ms are timed
+    assert j["timed_steps"] == 300 * j["repeats_of_the_steps_launch"] and j["timed_seconds"] >= 0.045
+    assert r["launches_timed"] >= 2 and r["launch_us"] * r["launches_timed"] >= 45e3
+    assert isinstance(j["config"]["csr_env_steps_per_s"], float) and j["config"]["csr_env_steps_per_s"] > 1e7
+    assert r["issue"] is None or (r["issue"]["bound"] == "valu-issue" and 0 < r["issue"]["frac"] < 1)
+    legs = j["configs"]
+    for k in ("tables_65536_random_rollout", "tables_65536_policy_loop_slab", "tables_65536_step_slab_only",
+              "tables_65536_rule_opponent"):
+        assert legs[k]["env_steps_per_s"] > 1e6, (k, legs)
+    ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
+    assert ret["up"] == ret["down"] == -ret["lord"] / 2 and ret["lord"] < -50  # rule farmers beat a random lord
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c
+
+
+def test_bench_two_ranks_rehearsal_gathers_the_union(pkg):
+    """The N > 1 control flow of bench.py (shard ids, packed trajectory gather to rank 0, two pipelined half-batches)
+    executed by two processes on this one GPU (gloo, host-staged: a rehearsal, not a measurement): the records rank 0
+    gathered equal a single-process rollout of the union of the two shards, record for record."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    T, K, W, KX = 512, 40, 10, 30
+    env_ = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"),
+                        "--gpus", "2", "--rehearse", "--strict-exchange", "--tables", str(T), "--steps", str(K),
+                        "--warmup", str(W), "--exchange-steps", str(KX)],
+                       capture_output=True, text=True, timeout=600, env=env_)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    ex = j["config"]["exchange"]
+    assert j["n_gpus"] == 2 and j["config"]["total_tables"] == 2 * T and "error" not in ex
+    assert ex["steps"] == KX and ex["bytes_to_rank0"] == KX * T * 8 and j["env_steps_per_s_with_gather"] > 0
+    env = pkg.BatchedEnv(2 * T, seed=0, device=_dev(), want_ids=False)
+    env.reset()
+    env.rollout_random(ex["iterations_before"])
+    half = KX // 2
+    ta = torch.zeros((half, 2 * T, 32), dtype=torch.uint8, device=_dev())
+    tb = torch.zeros((KX - half, 2 * T, 32), dtype=torch.uint8, device=_dev())
+    env.rollout_random(half, traj=ta)
+    env.rollout_random(KX - half, traj=tb)
+    x = torch.cat([pkg.pack_trajectory(ta), pkg.pack_trajectory(tb)]).contiguous().view(torch.int64).view(-1)
+    digest = int((x * 31 + (x >> 13) + torch.arange(x.numel(), device=_dev()) * x).sum().item())
+    assert digest == ex["digest"]

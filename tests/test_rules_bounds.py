@@ -1,13 +1,38 @@
 """CPU: bounds the engine's default sizing relies on (doudizhu-rl_amd/engine.py
 MAX_LEGAL_PER_TABLE = 512 rows per table), checked with the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
 import numpy as np
 
 FULL = np.array([4] * 13 + [1, 1])
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BOUND_SRC = os.path.join(REPO, "tools", "max_legal_bound.c")
+
+
+def test_497_is_the_exact_maximum_exhaustive(oracle, tmp_path):
+    """PROOF of the slab stride / STAGE_CAP sizing: tools/max_legal_bound.c enumerates all 153,009,740 count vectors of
+    20-card hands with a closed-form lead count (fewer cards / follows cannot have more, see its header).  The closed
+    form itself is checked against the oracle's dense scan first."""
+    so, exe = str(tmp_path / "bound.so"), str(tmp_path / "bound")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-DMAXLEGAL_NO_MAIN", "-o", so, BOUND_SRC])
+    L = ctypes.CDLL(so)
+    rng = np.random.default_rng(8)
+    deck = np.repeat(np.arange(15), FULL)
+    for k in range(1500):
+        n = 20 if k % 2 else int(rng.integers(1, 21))
+        h = np.bincount(rng.choice(deck, n, replace=False), minlength=15).astype(np.int8)
+        assert L.count_leads(h.ctypes.data_as(ctypes.c_void_p)) == len(oracle.legal(h)), h
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", exe, BOUND_SRC])
+    out = subprocess.check_output([exe], timeout=600).decode()
+    assert int(re.search(r"visited: (\d+)", out).group(1)) == 153009740
+    assert int(re.search(r"max legal leads: (\d+)", out).group(1)) == 497
 
 
 def test_known_worst_20_card_hand(oracle):
-    # 4 consecutive triples inside a 12-card straight: the maximum found by simulated
-    # annealing over 20-card hands (400 restarts x 1500 moves, always the same optimum)
+    # 4 consecutive triples inside a 12-card straight: a hand that attains the proven maximum
     worst = np.array([1, 1, 1, 1, 1, 3, 3, 3, 3, 1, 1, 1, 0, 0, 0], np.int8)
     assert worst.sum() == 20
     assert len(oracle.legal(worst)) == 497 < 512

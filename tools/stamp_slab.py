@@ -1,0 +1,47 @@
+"""Diagnostic: build the engine with -DDDZ_STAMP into build_variants/, run the slab API loop (step_slab(CHOICE)),
+report where k_table<F_STEP | F_SLAB> waves spend their cycles (s_memtime deltas per phase).  Not product."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "doudizhu-rl_amd", "csrc")
+out = os.path.join(ROOT, "build_variants")
+os.makedirs(out, exist_ok=True)
+lib = os.path.join(out, "stamp.so")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DDDZ_STAMP=1",
+                       "-o", lib, os.path.join(csrc, "ddz_engine.hip")])
+os.environ["DDZ_HIP_LIB"] = lib
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+pkg = importlib.import_module("doudizhu-rl_amd")
+raw = C.CDLL(lib)
+raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
+for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["4096", "65536"])]:
+    env = pkg.BatchedEnv(T, seed=0, want_ids=False)
+    env.reset()
+    env.rollout_random(60)
+    env.legal_slab()
+    choice = torch.zeros(T, dtype=torch.int32, device="cuda")
+    for _ in range(10):
+        env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+    buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
+    assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
+    env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+    torch.cuda.synchronize()
+    assert raw.ddz_debug_set_stamps(None) == 0
+    s = buf.cpu().numpy().astype(np.float64)
+    s = s[s[:, 5] > 0]
+    ntab = s[:, 5]
+    names = ["prologue loads issued", "hot fill + barrier", "decode (per table)", "select+apply+outputs (per table)",
+             "state store + new list (per table)"]
+    print(f"T={T}: {len(s)} waves, {ntab.mean():.1f} tables per wave; s_memtime cycles per wave")
+    for k, nm in enumerate(names):
+        per = s[:, k] / (ntab if k >= 2 else 1)
+        print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}")
+    print(f"  total per wave mean {s[:, :5].sum(1).mean():8.0f} cycles")
+    del env
