@@ -1105,6 +1105,285 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_slab: ONE lock-step iteration of a policy-driven loop in the slab layout (ddz_step_slab): apply the selections to
+// the lists the previous launch left in the slabs, then write the lists of the new states (game.py:95-106 +
+// envi.py:98-116).  Same semantics as k_table<F_STEP | F_SLAB> (which it replaces on this path), built like k_rollout:
+// k_table spent 315 scalar + 47 branch instructions per table-step and was bound by the ONE scalar unit of a CU
+// (16 waves x 360 scalar instructions = the measured 5.9 k cycles per round of 16 tables, profiles/r02_slab_*).  Here
+// the per-table decode is lane-parallel vector work (every lane packs and classifies its own row; the few values the
+// control flow needs are read with single readlanes), the chosen row of CHOICE is packed / classified by the lane
+// that prefetched it, and the new list is emitted by k_rollout's code (arithmetic fast path for follows of a single /
+// pair / triple, planner + LDS staging + coalesced flush otherwise).
+struct SlabArgs {
+  uint8_t* state;
+  int64_t T;
+  int tpw;
+  uint32_t k0, k1;
+  uint64_t gid_base;
+  int auto_reset;
+  const void* sel;      // CHOICE: int32[T] list index; ROWS: int8[T][16]; IDS: int32[T] action id (-1 = engine RNG)
+  int32_t* counts;      // [T] list sizes (in: lists of the current states, out: of the new states)
+  uint4* rows;          // [T][stride]
+  int32_t* ids;         // [T][stride] or null
+  int64_t stride;
+  uint8_t* done;
+  int8_t* reward;
+  uint8_t* illegal;
+  uint4* traj;          // [T][2] or null
+  int64_t* wave_stats;
+  int32_t* status;
+};
+
+// per-lane constants of the arithmetic follow list: lanes 0 pass | 1..15 group of rank lane-1 | 16..28 bomb | 29 rocket
+struct FastLanes {
+  int rr;
+  uint32_t bit, sh, w0, w1, w2, w3, grp, c4, rk;
+};
+__device__ __forceinline__ FastLanes fast_lanes(int lane) {
+  FastLanes f;
+  f.rr = (lane < 16 ? lane - 1 : lane - 16) & 15;
+  f.bit = lane < 32 ? 1u << lane : 0u;
+  f.sh = 8u * (uint32_t)(f.rr & 3);
+  f.w0 = (f.rr >> 2) == 0 ? ~0u : 0u; f.w1 = (f.rr >> 2) == 1 ? ~0u : 0u;
+  f.w2 = (f.rr >> 2) == 2 ? ~0u : 0u; f.w3 = (f.rr >> 2) == 3 ? ~0u : 0u;
+  f.grp = (lane >= 1 && lane < 16) ? ~0u : 0u;
+  f.c4 = (lane >= 16 && lane < 29) ? 4u : 0u;
+  f.rk = lane == 29 ? (0x00010100u | ((uint32_t)BIGBANG << 24)) : 0u;
+  asm volatile("" : "+v"(f.bit), "+v"(f.sh), "+v"(f.w0), "+v"(f.w1), "+v"(f.w2), "+v"(f.w3), "+v"(f.grp), "+v"(f.c4), "+v"(f.rk));
+  return f;
+}
+
+// the legal list of (hand, info) into the table's slab rows[base ...], ascending canonical id; returns its size
+template <bool IDS, class HT>
+__device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t base, int64_t stride, uint4* rows, int32_t* ids,
+                                         uint64_t* stage, uint16_t* svl, uint16_t* sid, const HT& hot, int lane,
+                                         const FastLanes& fl, int32_t* status) {
+  const int lc0 = (int)(info & 0xFF);
+  int n;
+  if (hand != 0 && lc0 != EMPTY && lc0 <= TRIPLE && !(info & (QF_FROZEN | QF_BADLAST))) {
+    // pass + the higher groups of the led size + bombs + rocket (card.py:307-325), one lane per candidate
+    const int lv0 = (int)((info >> 8) & 0xFF);
+    const int cntr = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
+    const uint32_t mlc = (uint32_t)__ballot(cntr >= lc0) & (lc0 == SINGLE ? M15 : M13);
+    const uint32_t mq = (uint32_t)__ballot(cntr >= 4) & M13;
+    const bool rocket = ((uint32_t)__ballot(cntr >= 1) & JOKERS) == JOKERS;
+    const uint32_t okm = 1u | ((mlc & gt_mask(lv0)) << 1) | (mq << 16) | (rocket ? 1u << 29 : 0u);
+    n = __builtin_popcount(okm);
+    const int pre = (int)__builtin_amdgcn_mbcnt_lo(okm, 0u);
+    const uint32_t copies = ((uint32_t)lc0 & fl.grp) | fl.c4;  // category == group size here
+    const uint32_t dv = copies << fl.sh;
+    const uint4 row = make_uint4(dv & fl.w0, dv & fl.w1, dv & fl.w2, (dv & fl.w3) | (copies << 24) | fl.rk);
+    if ((okm & fl.bit) != 0) {
+      rows[base + pre] = row;
+      if (IDS) ids[base + pre] = lane == 0 ? 0 : lane < 16 ? (lc0 == SINGLE ? 1 : lc0 == DOUBLE ? 16 : 29) + fl.rr
+                                 : lane < 29 ? 42 + fl.rr : ID_BIGBANG;
+    }
+  } else {
+    const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
+    Pick pk{-1, 0, 0, 0, 0};
+    n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
+    __builtin_amdgcn_wave_barrier();
+    if (n > STAGE_CAP || n > stride) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
+      if (lane == 0) atomicOr(status, 2);
+      n = 0;
+    }
+    for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
+      const uint64_t e = stage[j];
+      rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
+      if (IDS) ids[base + j] = sid[j];
+    }
+    __builtin_amdgcn_wave_barrier();  // the staging list is reused by the wave's next table
+  }
+  return n;
+}
+
+template <int MODE, bool IDS>
+__global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
+#ifdef DDZ_STAMP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  __shared__ HotTabT<false> hot;
+  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
+  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
+  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
+  const int64_t t0 = wave * a.tpw;
+  const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;
+  // every independent global load of the prologue is in flight before anything waits
+  uint4 Rnext = make_uint4(0, 0, 0, 0);
+  if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + t0 * STATE_ROW_BYTES))[lane];
+  int cnt_l = 0;          // lane i: size of the current list of table t0 + i
+  int32_t sel_l = -1;     // lane i: CHOICE index / IDS action id of table t0 + i
+  uint4 pre_row = make_uint4(0, 0, 0, 0);  // CHOICE: lane i prefetches the selected row of table t0 + i ...
+  if (lane < ntab) {
+    if (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) sel_l = ((const int32_t*)a.sel)[t0 + lane];
+    cnt_l = a.counts[t0 + lane];
+    if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
+    if (MODE == DDZ_STEP_CHOICE && sel_l >= 0 && sel_l < a.stride) pre_row = a.rows[(t0 + lane) * a.stride + sel_l];
+  }
+  hot_fill<TB>(hot);
+  __syncthreads();
+  TACC(0);
+  // ... and packs / classifies it (lane-parallel: the scalar unit is the bottleneck of this kernel)
+  uint32_t pre_info = 0;  // category | value << 8 | len << 16 | number of cards << 24
+  if (MODE == DDZ_STEP_CHOICE) {
+    if (sel_l < 0 || sel_l >= cnt_l) sel_l = -1;
+    const uint64_t pn = pack_row(pre_row);
+    pre_info = info_of_row(pn, (int)(pre_row.w >> 24)) | ((uint32_t)nib_sum(pn) << 24);
+  }
+  uint64_t* stage = s_stage[wv];
+  uint16_t* svl = s_svl[wv];
+  uint16_t* sid = s_sid[IDS ? wv : 0];
+  const FastLanes fl = fast_lanes(lane);
+  int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
+  int64_t s_rows = 0;
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
+    uint4 R = Rnext;  // lane f < 11 holds row f of the table
+    if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
+    // ---- decode, lane-parallel: every lane packs and classifies its own row
+    const uint64_t P = pack_row(R);
+    const uint32_t infoL = info_of_row(P, (int)((R.w >> 24) & 15));   // meaningful on the recent-handout rows
+    const uint32_t nz = (uint32_t)__ballot(P != 0);                    // bit f: row f holds cards
+    const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
+    int role = mx & 0xFF;
+    if (role > 2) role = 0;  // never index outside the table on a corrupted import
+    bool is_done = (mx >> 8) & 0xFF;
+    const bool dealt = (my >> 16) & 0xFF;
+    uint32_t ply = my & 0xFFFF, episode = mz;
+    const uint64_t gid = a.gid_base + (uint64_t)t;
+    const bool active = dealt && !is_done;
+    const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+    // the combo the current actor has to beat (envi.py:103-109): previous player's handout, else the one before
+    const int lsrc = ((nz >> (DDZ_F_RECENT0 + rm1)) & 1u) ? DDZ_F_RECENT0 + rm1 : DDZ_F_RECENT0 + rp1;
+    const uint32_t cur_info = ((nz >> lsrc) & 1u) ? rl(infoL, lsrc) : mk_info(EMPTY, 0, 1);
+    const int A = (int)rl((uint32_t)cnt_l, i);
+    const bool frozen = !active || A <= 0;
+    // ---- selection
+    int idx = -1;
+    uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, the same value in every lane
+    uint32_t cinfo = 0;                 // its category | value << 8 | len << 16 | number of cards << 24
+    const int32_t sel_i = (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) ? (int32_t)rl((uint32_t)sel_l, i) : 0;
+    if (!frozen) {
+      if (MODE == DDZ_STEP_CHOICE) {
+        idx = sel_i;
+        if (idx >= 0) {
+          c = make_uint4(rl(pre_row.x, i), rl(pre_row.y, i), rl(pre_row.z, i), rl(pre_row.w, i));
+          cinfo = rl(pre_info, i);
+        }
+      } else {
+        if (MODE == DDZ_STEP_RANDOM || (MODE == DDZ_STEP_IDS && sel_i == -1)) {  // random.choice(actions), envi.py:83
+          const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
+          idx = (int)__umulhi(rfl(d.x), (uint32_t)A);
+        } else {  // wave-parallel search of the list for the wanted counts
+          constexpr int NIDS = DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS;
+          const bool id_ok = MODE != DDZ_STEP_IDS || (sel_i >= 0 && sel_i < NIDS);
+          const uint4 want = MODE == DDZ_STEP_IDS ? row_of_id(id_ok ? sel_i : 0) : ((const uint4*)a.sel)[t];
+          for (int j0 = 0; j0 < A && idx < 0 && id_ok; j0 += 64) {
+            bool hit = false;
+            if (j0 + lane < A) {
+              const uint4 r = a.rows[t * a.stride + j0 + lane];
+              hit = r.x == want.x && r.y == want.y && r.z == want.z && ((r.w ^ want.w) & 0x00FFFFFFu) == 0;
+            }
+            const uint64_t hb = __ballot(hit);
+            if (hb) idx = j0 + __builtin_ctzll(hb);
+          }
+        }
+        if (idx >= 0) {  // every lane loads the same row: it stays in vector registers, no scalar unpacking
+          const uint4 r = a.rows[t * a.stride + idx];
+          const uint64_t pn = pack_row(r);
+          c = make_uint4(rfl(r.x), rfl(r.y), rfl(r.z), rfl(r.w));
+          cinfo = rfl(info_of_row(pn, (int)(r.w >> 24)) | ((uint32_t)nib_sum(pn) << 24));
+        }
+      }
+    }
+    TACC(2);
+    // ---- apply (envi.py:38-43 _update + native step), outputs, trajectory record
+    uint4 tr0 = make_uint4(0, 0, 0, 0);
+    uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)A & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
+    uint32_t o_done = is_done, o_illegal = 0, o_reward = 0;
+    bool live = active;                                        // is there a list to write afterwards
+    uint64_t qhand = 0;                                        // ... and for which (hand, combo to beat)
+    uint32_t qinfo = cur_info;
+    bool changed = false;
+    if (frozen) {
+      tr1.x |= (uint32_t)is_done << 8 | 2u << 24;
+      if (active) qhand = rl64(P, DDZ_F_HAND0 + role);  // a live table whose list was reported empty: write it afresh
+    } else if (idx < 0) {  // not in the list: table untouched, flagged; its list is written again as it was
+      o_done = 0; o_illegal = 1;
+      tr1.x |= 1u << 24;
+      qhand = rl64(P, DDZ_F_HAND0 + role);
+    } else {
+      changed = true;
+      const uint32_t ncards = cinfo >> 24;
+      const uint32_t cw3 = c.w & 0x00FFFFFFu;
+      const uint32_t left_before = rl(R.w, DDZ_F_HAND0 + role) >> 24;
+      // byte-wise: every byte of the hand >= the row's byte, so no borrow/carry crosses a byte
+      if (lane == DDZ_F_HAND0 + role) {
+        R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
+      } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
+        R.x += c.x; R.y += c.y; R.z += c.z; R.w += cw3;
+      } else if (lane == DDZ_F_RECENT0 + role) {
+        R = c;
+      }
+      const bool won = left_before == ncards;
+      o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14: -1 lord won, +1 farmers
+      o_done = won;
+      s_ply += 1; s_eps += won; s_lord += (won && role == 1); s_up += (won && role == 0);
+      tr0 = c;
+      tr1.x |= (uint32_t)won << 8 | o_reward << 16;
+      tr1.w = (uint32_t)idx;
+      ply += 1;
+      if (won && a.auto_reset) {
+        episode += 1;
+        uint64_t h0, h1, h2;
+        deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
+        R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+            : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
+        qhand = h1; qinfo = mk_info(EMPTY, 0, 1);  // the lord leads
+      } else {
+        if (lane == DDZ_F_META)
+          R = make_uint4((uint32_t)rp1 | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) | (o_reward << 24),
+                         (my & 0xFFFF0000u) | (ply & 0xFFFF), mz, R.w);
+        live = !won;
+        // the next actor (lord -> down -> up, game.py:173-181) has to beat this ply's combo, or -- after a pass -- the
+        // previous player's: its hand is untouched by this ply
+        qhand = rl64(P, DDZ_F_HAND0 + rp1);
+        if (ncards) qinfo = cinfo & 0x00FFFFFFu;
+        else qinfo = ((nz >> (DDZ_F_RECENT0 + rm1)) & 1u) ? rl(infoL, DDZ_F_RECENT0 + rm1) : mk_info(EMPTY, 0, 1);
+      }
+    }
+    if (lane == 0) {
+      if (a.done) a.done[t] = (uint8_t)o_done;
+      if (a.reward) a.reward[t] = (int8_t)o_reward;
+      if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
+    }
+    if (a.traj && lane < 2) a.traj[2 * t + lane] = sel4(lane == 0, tr0, tr1);
+    if (changed && lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
+    TACC(3);
+    // ---- the list of the (new) state, straight into the table's slab
+    int n = 0;
+    if (live) n = slab_list<IDS>(qhand, rfl(qinfo), t * a.stride, a.stride, a.rows, a.ids, stage, svl, sid, hot, lane, fl, a.status);
+    if (lane == 0) a.counts[t] = n;
+    s_rows += n;
+    TACC(4);
+  }
+#ifdef DDZ_STAMP
+  if (g_stamps && lane == 0 && ntab > 0) {
+    tacc[5] = ntab;
+    for (int q = 0; q < 8; ++q) g_stamps[16 * t0 + q] = tacc[q];
+  }
+#endif
+  if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
+    int64_t* ws = a.wave_stats + 4 * wave;
+    ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // k_mask: the legal moves of every table as a dense 0/1 mask over the action space -- the form the reference's
 // rules produce (get_mask, rule_based/utils/utils.py:45-63; mask[0] = pass) and what a policy head with one logit
 // per action consumes.  Bit-packed: MASK_WORDS u32 per table, bit (id & 31) of word id >> 5.  One wavefront per
@@ -1227,30 +1506,50 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
 }
 
 // action selection of DQNFirst.greedy_action / e_greedy_action (dqn.py:50-71) for every table:
-// choice = first index of the maximum q of the table's CSR segment (torch.argmax, dqn.py:60,70);
-// with probability epsilon (engine RNG domain 3, one Philox call per table and ply) a uniform
-// index instead (dqn.py:57-58).  thr = floor(epsilon * 2^32): explore <=> draw.x < thr.
+// choice = first index of the maximum q of the table's list (torch.argmax, dqn.py:60,70); with probability epsilon
+// (engine RNG domain 3, one Philox call per table and ply) a uniform index instead (dqn.py:57-58).
+// thr = floor(epsilon * 2^32): explore <=> draw.x < thr.
+// Sixteen lanes per table: lane s reads entries s, s + 16, ... of the segment (consecutive lanes read consecutive
+// floats: coalesced whatever the list size; the slab form used to stride 2 KB per thread), then a 4-step butterfly
+// keeps (larger value, on ties the smaller index).
+constexpr int SEL_G = 16;
 __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ state, int64_t T, uint32_t k0, uint32_t k1,
                                                   uint64_t gid_base, const float* __restrict__ q,
                                                   const int32_t* __restrict__ offsets, uint64_t thr,
                                                   int32_t* __restrict__ choice, const int32_t* __restrict__ counts,
                                                   int64_t stride) {
-  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= T) return;
+  const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t t = gtid / SEL_G;
+  const int sub = (int)(gtid % SEL_G);
+  if (t >= T) return;  // whole 16-lane groups leave together (BLOCK is a multiple of 16)
   // CSR: segment [offsets[t], offsets[t+1]); slab (counts != null): [t * stride, t * stride + counts[t])
   const int64_t off = counts ? t * stride : (int64_t)offsets[t];
   int32_t A = counts ? counts[t] : offsets[t + 1] - offsets[t];
   if (counts && A > stride) A = 0;
   if (A <= 0) {
-    choice[t] = -1;
+    if (sub == 0) choice[t] = -1;
     return;
   }
-  int best = 0;
-  float bq = q[off];
-  for (int j = 1; j < A; ++j) {
+  // lane-local first maximum over j = sub, sub + 16, ...; a lane without an entry holds index INT_MAX
+  int best = 0x7FFFFFFF;
+  float bq = 0.f;
+  for (int j = sub; j < A; j += SEL_G) {
     const float v = q[off + j];
-    if (v > bq) { bq = v; best = j; }
+    // the sequential rule "replace when strictly greater": a NaN never replaces anything, and a NaN in entry 0 is
+    // never replaced -- so NaNs behind entry 0 are skipped here, entry 0 is taken as it is
+    if (j == 0 || (v == v && (best == 0x7FFFFFFF || v > bq))) { bq = v; best = j; }
   }
+#pragma unroll
+  for (int d = 1; d < SEL_G; d <<= 1) {
+    const float oq = __shfl_xor(bq, d, SEL_G);
+    const int ob = __shfl_xor(best, d, SEL_G);
+    // the sequential scan keeps the first entry unless a later one is strictly greater (dqn.py:60 torch.argmax on
+    // distinct values; NaNs never win): between two candidates the earlier index stays unless the later is greater
+    const bool have = best != 0x7FFFFFFF, ohave = ob != 0x7FFFFFFF;
+    const bool take = ohave && (!have || (ob < best ? !(bq > oq) : (oq > bq)));
+    if (take) { bq = oq; best = ob; }
+  }
+  if (sub != 0) return;
   if (thr) {
     const uint4 meta = *(const uint4*)(state + t * STATE_ROW_BYTES + DDZ_F_META * 16);
     const uint64_t gid = gid_base + (uint64_t)t;
@@ -1740,16 +2039,28 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   if (mode != DDZ_STEP_RANDOM && !sel) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
-  Io io;
-  io.sel = sel; io.rows = rows; io.ids = ids; io.slab_counts = counts; io.stride = stride;
-  io.auto_reset = auto_reset ? 1 : 0; io.done = done; io.reward = reward; io.illegal = illegal; io.traj = traj;
+  SlabArgs a;
+  a.state = e->state; a.T = e->T; a.tpw = e->tpw;
+  a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
+  a.auto_reset = auto_reset ? 1 : 0; a.sel = sel; a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride;
+  a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
+  a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)e->nblocks), block(TB);
+#define DDZ_LAUNCH_SLAB(M)                                                              \
+  do {                                                                                  \
+    if (ids) hipLaunchKernelGGL((k_slab<M, true>), grid, block, 0, st, a);              \
+    else hipLaunchKernelGGL((k_slab<M, false>), grid, block, 0, st, a);                 \
+  } while (0)
   switch (mode) {
-    case DDZ_STEP_RANDOM: return launch_table<F_STEP | F_SLAB, DDZ_STEP_RANDOM>(e, io, st);
-    case DDZ_STEP_CHOICE: return launch_table<F_STEP | F_SLAB, DDZ_STEP_CHOICE>(e, io, st);
-    case DDZ_STEP_IDS: return launch_table<F_STEP | F_SLAB, DDZ_STEP_IDS>(e, io, st);
-    default: return launch_table<F_STEP | F_SLAB, DDZ_STEP_ROWS>(e, io, st);
+    case DDZ_STEP_RANDOM: DDZ_LAUNCH_SLAB(DDZ_STEP_RANDOM); break;
+    case DDZ_STEP_CHOICE: DDZ_LAUNCH_SLAB(DDZ_STEP_CHOICE); break;
+    case DDZ_STEP_IDS: DDZ_LAUNCH_SLAB(DDZ_STEP_IDS); break;
+    default: DDZ_LAUNCH_SLAB(DDZ_STEP_ROWS); break;
   }
+#undef DDZ_LAUNCH_SLAB
+  e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
+  return check_launch();
 }
 
 int ddz_mask_words(void) { return MASK_WORDS; }
@@ -1991,7 +2302,7 @@ int ddz_select(ddz_env_t* e, const float* q, const int32_t* offsets, double epsi
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   const uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
-  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T * SEL_G + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q, offsets,
                      thr, choice, (const int32_t*)nullptr, (int64_t)0);
   return check_launch();
@@ -2005,7 +2316,7 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   const uint64_t thr = (uint64_t)(epsilon * 4294967296.0);
-  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T * SEL_G + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q,
                      (const int32_t*)nullptr, thr, choice, counts, stride);
   return check_launch();

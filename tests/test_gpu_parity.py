@@ -387,6 +387,46 @@ def test_select_matches_argmax_and_oracle(pkg, oracle, eps):
         assert explored > 0
 
 
+def test_select_long_lists_ties_and_nans(pkg, oracle):
+    """k_select reads a list with 16 lanes and merges them: on lead states with long lists (up to ~130 moves), values
+    from a 3-level set (ties across lanes) and sprinkled NaNs, CSR and slab forms pick what the sequential scan of
+    dqn.py:60's arg-max does (first maximum; a NaN never replaces, a NaN in entry 0 stays)."""
+    T = 2048
+    env = pkg.BatchedEnv(T, seed=8, device=_dev())
+    ref = oracle.OracleEnv(T, seed=8)
+    env.reset(); ref.reset()                       # every table: the lord leads with 20 cards
+    g = torch.Generator().manual_seed(5)
+    for it in range(6):
+        offsets, _, _ = env.legal()
+        roff, _, _ = ref.legal()
+        n = int(roff[-1])
+        cnt = np.diff(roff)
+        if it == 0:
+            assert cnt.max() > 64 and cnt.min() > 16
+        q = torch.randint(0, 3, (n,), generator=g).float()
+        q[torch.rand(n, generator=g) < 0.05] = float("nan")
+        q[torch.from_numpy(roff[:-1][::5].astype(np.int64))] = float("nan")   # entry 0 of every fifth table
+        want = ref.select(q.numpy(), 0.0)
+        seq = np.zeros(T, np.int32)
+        qn = q.numpy()
+        for t in range(T):
+            b = 0
+            for j in range(1, cnt[t]):
+                if qn[roff[t] + j] > qn[roff[t] + b]:
+                    b = j
+            seq[t] = b
+        assert np.array_equal(want, seq)
+        assert np.array_equal(env.select(q.to(_dev())).cpu().numpy(), want)
+        counts, _, _ = env.legal_slab()
+        qs = torch.full((T, env.slab_stride), 7.0)
+        for t in range(T):
+            qs[t, :cnt[t]] = q[roff[t]:roff[t + 1]]
+        assert np.array_equal(env.select_slab(qs.to(_dev())).cpu().numpy(), want)
+        env.step_slab(torch.from_numpy(want), pkg.STEP_CHOICE, auto_reset=False)
+        ref.step(oracle.STEP_CHOICE, want, auto_reset=False)
+        env.reset(); ref.reset()                   # next episode: new 20-card leads
+
+
 def test_step_onehot_matches_step_choice(pkg):
     """batched step_manual with [T,15,4] thermometer actions == stepping by list index"""
     T = 1024

@@ -1,5 +1,5 @@
 """Diagnostic: build the engine with -DDDZ_STAMP into build_variants/, run the slab API loop (step_slab(CHOICE)),
-report where k_table<F_STEP | F_SLAB> waves spend their cycles (s_memtime deltas per phase).  Not product."""
+report where k_slab's waves spend their cycles (s_memtime deltas per phase).  Not product."""
 import ctypes as C
 import importlib
 import os
@@ -37,8 +37,8 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
     s = buf.cpu().numpy().astype(np.float64)
     s = s[s[:, 5] > 0]
     ntab = s[:, 5]
-    names = ["prologue loads issued", "hot fill + barrier", "decode (per table)", "select+apply+outputs (per table)",
-             "state store + new list (per table)"]
+    names = ["prologue loads + hot fill + barrier", "-", "decode + selection (per table)",
+             "apply + outputs + state store (per table)", "list of the new state (per table)"]
     print(f"T={T}: {len(s)} waves, {ntab.mean():.1f} tables per wave; s_memtime cycles per wave")
     for k, nm in enumerate(names):
         per = s[:, k] / (ntab if k >= 2 else 1)
