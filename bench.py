@@ -151,21 +151,23 @@ def issue_roofline(steps_timed, dur_launch):
             cyc[r["kind"]] = r["cycles_per_instr_per_simd"]
     full = (cyc["v_add_u32"] + cyc["v_and_b32/v_or_b32"]) / 2            # plain 32-bit VALU
     half = (cyc["v_lshlrev_b64"] + cyc["v_add_co_u32+v_addc_co_u32"] + cyc["v_sub_co_u32+v_subb_co_u32"]
-            + cyc["v_mul_lo_u32"] + cyc["v_mbcnt_lo+v_mbcnt_hi"]) / 5   # 64-bit shifts, carry chains, mul, mbcnt
-    mix = prof.get("valu_mix")  # measured share of the slow classes (profiles, SQ_INSTS_VALU_INT64 ...), if collected
-    share_half = mix["share_half_rate"] if mix else 0.5
-    cpi = (1 - share_half) * full + share_half * half
+            + cyc["v_mul_lo_u32"] + cyc["v_mbcnt_lo+v_mbcnt_hi"]) / 5   # 64-bit shifts, carry chains, mul, mbcnt, compares
+    lane = cyc["v_readlane_b32"]                                          # v_readlane / v_readfirstlane
+    mix = prof.get("valu_mix") or {"share_half_rate": 0.5, "share_readlane": 0.0, "source": "assumed"}
+    sh, sr = mix["share_half_rate"], mix.get("share_readlane", 0.0)
+    cpi = (1 - sh - sr) * full + sh * half + sr * lane
     simds = 256 * 4
     peak = simds * v["clock_GHz"] * 1e9 / cpi
     ach = v["SQ_INSTS_VALU_per_env_step"] * steps_timed / dur_launch
     return {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
             "valu_insts_per_env_step": v["SQ_INSTS_VALU_per_env_step"], "cycles_per_instr_full_rate": full,
-            "cycles_per_instr_half_rate": half, "share_half_rate": share_half,
-            "share_source": "measured (profiles/pmc_traffic.json valu_mix)" if mix else "assumed 0.5",
+            "cycles_per_instr_half_rate": half, "cycles_per_instr_readlane": lane, "share_half_rate": sh,
+            "share_readlane": sr, "mix_weighted_cycles_per_instr": cpi, "share_source": mix.get("source", "")[:160],
             "peak_if_all_full_rate": simds * v["clock_GHz"] / full, "peak_if_all_half_rate": simds * v["clock_GHz"] / half,
             "note": "cycles per wave64 instruction per SIMD measured by tools/valu_issue_probe.hip at 4 waves/SIMD "
                     "(profiles/r02_valu_issue_probe.json): ~2.4 for plain 32-bit ops (the guide's 2-cycle SIMD-32 figure), "
-                    "~4.5 for 64-bit shifts / carry chains / v_mul_lo / v_mbcnt, which the nibble-SWAR code is made of"}
+                    "~4.5 for 64-bit shifts / carry chains / v_mul_lo / v_mbcnt / compares, ~6.3 for v_readlane; the peak "
+                    "weights them by the kernel's opcode mix"}
 
 
 def main():

@@ -1,0 +1,494 @@
+// ddz_auto2.h -- k_auto2: the rule-based opponent's search (see ddz_auto.h for what is computed and which reference
+// files it restates) with the 64 LANES of the table's wavefront searching different subtrees.
+//
+// k_auto (ddz_auto.h) walks the decomposition tree with wave-uniform control: one node at a time, ~0.7 us per node, and
+// a launch lasts as long as its single heaviest table (10-card hands reach 10^5 nodes: 12 ms).  Here, per table:
+//   1. candidates as before (plan_scan lead enumeration -> LDS), then sorted IN PLACE by (lowest rank, id) through
+//      registers: cn[pos] = nib, ci[pos] = id | value x 2 | fine_mask bit; bstart[r] = first position of rank r's bucket;
+//   2. frontier: starting from the root, lane-parallel expansion passes replace nodes by their children IN PLACE
+//      (children counts -> wave prefix sums -> positions), the nodes with the most cards left first, as long as the
+//      list fits 448 items.  The list is always an ordered cut of the tree: item k's subtree precedes item k + 1's in
+//      depth-first order; small trees end up as a list of finished combinations;
+//   3. search: lanes take items (largest index first: the unexpanded, larger subtrees sit at the end) and walk their
+//      subtree depth-first with a private stack (one packed u32 per level in LDS) -- one candidate test or one
+//      descend / backtrack per loop trip, so that divergent lanes stay cheap;
+//   4. every lane keeps (value, item index, move) of its best scored combination; inside an item the strict `>` of
+//      rule_based_model.py keeps the first maximum, across items the SMALLER item index wins a tie: together exactly
+//      "first maximum in depth-first order", the order the combinations are listed in by decomposer spec v1.
+// Tables are assigned to waves round-robin (t = wave, wave + n_waves, ...): heavy tables average out over a wave's share.
+// Included by ddz_engine.hip after ddz_auto.h.
+#pragma once
+
+constexpr int A2_WPB = 4;       // waves per block (the frontier needs LDS: ~34 KB per wave)
+constexpr int A2_TB = A2_WPB * 64;
+constexpr int A2_CAP = 448;     // frontier items per table
+constexpr int A2_PASSES = 12;   // expansion passes at most
+constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
+constexpr int A2_NOFROM = 1023;
+
+struct Auto2Wave {              // per wave
+  uint64_t cn[STAGE_CAP];       // candidates: nibble-packed counts (during staging: nib | category << 60, unsorted)
+  uint32_t ci[STAGE_CAP];       // id | (value x 2 & 0xFF) << 14 | fine_mask << 22   (during staging: two u16 arrays)
+  uint64_t itA[2][A2_CAP];      // frontier items (double buffer): remaining hand / untouched ranks
+  uint64_t itB[2][A2_CAP];      //   pending surplus of the touched ranks (> 10 cards)
+  uint32_t itM[2][A2_CAP];      //   (sum2 + 512) | (cvmin & 0xFF) << 10 | actions so far << 18
+  uint32_t itI[2][A2_CAP];      //   idmin | first allowed position << 14 (A2_NOFROM = bucket start)
+  uint32_t stack[A2_DEPTH][64]; // per lane: code | (cvmin & 0xFF) << 10 | idmin << 18 of the level's parent
+  int32_t hist[24];             // frontier pass: extra slots wanted by the items with c cards left
+  uint16_t tcnt[A2_CAP];        //   children of item i
+  uint8_t tcards[A2_CAP];       //   cards left of item i
+  uint16_t bstart[16];
+};
+
+struct A2Ctx {                  // wave-uniform facts of the query
+  uint64_t hand;
+  uint32_t esingle, epair;
+  bool nosplit, follow, pass_ok;
+  double rp;
+};
+
+__device__ __forceinline__ int a2_lowrank(uint64_t x) { return x ? (__builtin_ctzll(x) >> 2) : 16; }
+__device__ __forceinline__ bool a2_fits(uint64_t nib, uint64_t a) {
+  constexpr uint64_t H8 = 0x8888888888888888ull;
+  return (((a | H8) - nib) & H8) == H8;
+}
+__device__ __forceinline__ uint64_t a2_rankmask(uint64_t nib) {  // 0xF on every rank the action touches
+  uint64_t tm = nib | (nib >> 1);
+  tm |= tm >> 2;
+  return (tm & ONES) * 15ull;
+}
+// child of a regular node after playing candidate `nib`
+__device__ __forceinline__ void a2_child(const A2Ctx& q, uint64_t A, uint64_t B, uint64_t nib, uint64_t& A2, uint64_t& B2) {
+  if (q.nosplit) {
+    const uint64_t rm = a2_rankmask(nib);
+    A2 = A & ~rm;
+    B2 = B + (A & rm) - nib;  // what the action leaves of the ranks it touches
+  } else {
+    A2 = A - nib;
+    B2 = 0;
+  }
+}
+__device__ __forceinline__ int a2_single_v2(int r) { return 2 * (r - 7); }
+__device__ __forceinline__ int a2_pair_v2(int r) { return r - 7 > 0 ? 3 * (r - 7) : 2 * (r - 7); }
+
+template <bool STATE>
+__global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
+  __shared__ HotTabT<false> hot;
+  __shared__ Auto2Wave s_w[A2_WPB];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t wave0 = (int64_t)blockIdx.x * A2_WPB + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * A2_WPB;
+  hot_fill<A2_TB>(hot);
+  __syncthreads();
+  Auto2Wave& W = s_w[wv];
+  uint16_t* svl = (uint16_t*)W.ci;               // staging views of ci: value | len << 8 ...
+  uint16_t* sid = (uint16_t*)W.ci + STAGE_CAP;    // ... and the canonical ids
+  constexpr uint64_t NIBM = 0x0FFFFFFFFFFFFFFFull;
+  for (int64_t t = wave0; t < a.T; t += nwaves) {
+    // ---- the query: hand, combo to beat, cards left, acting role (as k_auto)
+    uint64_t hand;
+    uint32_t linfo;
+    int role, left0, left1, left2;
+    bool active;
+    if (STATE) {
+      uint4 R = make_uint4(0, 0, 0, 0);
+      if (lane < DDZ_NFIELDS) R = ((const uint4*)(a.state + t * STATE_ROW_BYTES))[lane];
+      const uint64_t P = pack_row(R);
+      const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META);
+      role = mx & 0xFF;
+      active = ((my >> 16) & 0xFF) && !((mx >> 8) & 0xFF) && role <= 2 && ((a.auto_roles >> role) & 1);
+      if (role > 2) role = 0;
+      const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+      hand = rl64(P, DDZ_F_HAND0 + role);
+      linfo = last_info(rl64(P, DDZ_F_RECENT0 + rm1), (int)(rl(R.w, DDZ_F_RECENT0 + rm1) >> 24),
+                        rl64(P, DDZ_F_RECENT0 + rp1), (int)(rl(R.w, DDZ_F_RECENT0 + rp1) >> 24));
+      left0 = (int)(rl(R.w, DDZ_F_HAND0) >> 24); left1 = (int)(rl(R.w, DDZ_F_HAND0 + 1) >> 24);
+      left2 = (int)(rl(R.w, DDZ_F_HAND0 + 2) >> 24);
+    } else {
+      const uint4 hr = a.hands[t], lr = a.lasts[t];
+      hand = pack_row(make_uint4(rfl(hr.x), rfl(hr.y), rfl(hr.z), rfl(hr.w)));
+      linfo = classify(pack_row(make_uint4(rfl(lr.x), rfl(lr.y), rfl(lr.z), rfl(lr.w))));
+      const uint32_t qq = rfl(a.info[t]);
+      left0 = qq & 0xFF; left1 = (qq >> 8) & 0xFF; left2 = (qq >> 16) & 0xFF; role = (int)(qq >> 24);
+      active = true;
+      if (linfo == INFO_INVALID || ge_mask(hand, 5) || (hand >> 60) || role > 2) {  // no combo of the action space
+        if (lane == 0 && a.status) atomicOr(a.status, 4);
+        active = false;
+      }
+    }
+    if (!active || hand == 0) {
+      if (lane == 0) {
+        a.ids[t] = -1;
+        if (a.stats) { a.stats[2 * t] = 0; a.stats[2 * t + 1] = 0; }
+      }
+      continue;
+    }
+#ifdef DDZ_STAMP
+    unsigned long long tq[6];
+    tq[0] = __builtin_amdgcn_s_memtime();
+#endif
+    const Follow f = follow_of(linfo);
+    A2Ctx q;
+    q.hand = hand;
+    q.follow = !f.lead;
+    // rule_based_model.py:56-57 (the role test is the reference's own: role 0 looks at lord and down, the others at up)
+    int min_opp = role == 0 ? (left1 < left2 ? left1 : left2) : left0;
+    if (min_opp > 23) min_opp = 23;
+    q.rp = a.rp[min_opp];
+    q.pass_ok = min_opp > 4;
+    q.nosplit = nib_sum(hand) > 10;  // decomposer.py:18
+    q.esingle = !q.follow ? M15 : (f.lc == SINGLE ? gt_mask(f.lv) : 0u);
+    q.epair = !q.follow ? M13 : (f.lc == DOUBLE ? (gt_mask(f.lv) & M13) : 0u);
+
+    // ---- 1. candidates: every action that fits the hand (decomposer.py:19-28 valid_row_idx / :50-55 valid)
+    __builtin_amdgcn_wave_barrier();
+    int n;
+    {
+      const Out o{nullptr, nullptr, 0, 0, W.cn, svl, sid};
+      Pick pk{-1, 0, 0, 0, 0};
+      n = plan_scan<EM_STAGE, true>(hand, mk_info(EMPTY, 0, 1), hot, lane, o, pk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (n > STAGE_CAP) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
+      if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = -1; }
+      continue;
+    }
+    // per candidate (lane holds entries lane, lane + 64, ...: at most 8): value x 2, fine_mask, lowest rank
+    constexpr int PER = (STAGE_CAP + 63) / 64;
+    uint64_t e_nib[PER];
+    uint32_t e_ci[PER];
+    int e_lr[PER];
+    int cnt_lane = 0;  // lane r: number of candidates whose lowest rank is r
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = u * 64 + lane;
+      e_lr[u] = 16; e_nib[u] = 0; e_ci[u] = 0;
+      if (j < n) {
+        const uint64_t e = W.cn[j];
+        const uint64_t nib = e & NIBM;
+        const int cat = (int)(e >> 60), vl = svl[j], val = vl & 0xFF, len = vl >> 8;
+        const int v2 = auto_val2(nib, cat, val, len);
+        const bool el = !q.follow || auto_beats(cat, val, len, f);
+        e_nib[u] = nib;
+        e_ci[u] = (uint32_t)sid[j] | ((uint32_t)(v2 & 0xFF) << 14) | (el ? 1u << 22 : 0u);
+        e_lr[u] = __builtin_ctzll(nib) >> 2;
+      }
+      if (u * 64 < n) {
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+          const int c = __popcll(__ballot(e_lr[u] == r));
+          if (lane == r) cnt_lane += c;
+        }
+      }
+    }
+    const int start_lane = wave_incl_scan(lane < 15 ? cnt_lane : 0, lane) - (lane < 15 ? cnt_lane : 0);
+    int run_lane = start_lane;
+    __builtin_amdgcn_wave_barrier();  // every entry is in registers: the arrays may be overwritten in sorted order
+    if (lane < 16) W.bstart[lane] = (uint16_t)start_lane;  // lane 15: n
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (u * 64 < n) {
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+          const uint64_t m = __ballot(e_lr[u] == r);
+          if (m) {  // wave-uniform
+            const int base = (int)rl((uint32_t)run_lane, r);
+            const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (e_lr[u] == r) { W.cn[base + pre] = e_nib[u]; W.ci[base + pre] = e_ci[u]; }
+            if (lane == r) run_lane += __popcll(m);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- helpers on a node (A, B): the lowest uncovered slot decides its kind
+    auto pend_rank = [&](uint64_t A, uint64_t B) -> int {  // >= 0: a surplus card of that touched rank leaves next
+      const int ul = a2_lowrank(A), pl = a2_lowrank(B);
+      return pl < ul ? pl : -1;
+    };
+    auto pair_option = [&](uint64_t B, int pr) -> bool {     // augmented pair of slots 2, 3 (card.py:544-547)
+      return ((B >> (4 * pr)) & 15) == 2 && ((q.hand >> (4 * pr)) & 15) == 4;
+    };
+
+#ifdef DDZ_STAMP
+    tq[1] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- 2. frontier: an ordered cut of the tree.  Every pass replaces nodes by their children in place (order kept),
+    // the nodes with the MOST cards left first (their subtrees are the largest), as long as the list fits.
+    int nitems = 1, cur = 0;
+    int nodes_l = lane == 0 ? 1 : 0, combs_l = 0;
+    if (lane == 0) {
+      W.itA[0][0] = hand; W.itB[0][0] = 0;
+      W.itM[0][0] = 512u | ((uint32_t)(AUTO_NONE & 0xFF) << 10);
+      W.itI[0][0] = (uint32_t)A2_NOFROM << 14;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int pass = 0; pass < A2_PASSES; ++pass) {
+      // (a) children count and cards left of every item; extra slots wanted per cards-left class
+      if (lane < 24) W.hist[lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      for (int i0 = 0; i0 < nitems; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < nitems) {
+          const uint64_t A = W.itA[cur][i], B = W.itB[cur][i];
+          const uint32_t I = W.itI[cur][i];
+          int cnt = 1, cards = 0;  // a finished combination stays as it is
+          if ((A | B) != 0) {
+            cards = nib_sum(A) + nib_sum(B);
+            const int pr = pend_rank(A, B);
+            if (pr >= 0) {
+              cnt = 1 + (pair_option(B, pr) ? 1 : 0);
+            } else {
+              const int ul = a2_lowrank(A), from = (int)((I >> 14) & 1023);
+              const int lo = from != A2_NOFROM ? from : (int)W.bstart[ul], hi = (int)W.bstart[ul + 1];
+              cnt = 0;
+              for (int p = lo; p < hi; ++p) cnt += a2_fits(W.cn[p], A) ? 1 : 0;
+            }
+            atomicAdd(&W.hist[cards], cnt - 1);
+          }
+          W.tcnt[i] = (uint16_t)cnt;
+          W.tcards[i] = (uint8_t)cards;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // (b) classes above tau expand entirely, class tau as far as the budget goes (a prefix, in item order)
+      const int budget = A2_CAP - nitems;
+      int tau = 21, used = 0;
+      for (int c = 20; c >= 1; --c) {
+        const int h = W.hist[c];
+        if (used + h > budget) { tau = c; break; }
+        used += h;
+        tau = c;
+        if (c == 1) tau = 0;  // everything fits
+      }
+      int mleft = budget - used;  // for the marginal class tau (when tau >= 1 and it did not fit entirely)
+      const bool marginal_partial = tau >= 1 && used + W.hist[tau] > budget;
+      // (c) emit
+      const int nxt = cur ^ 1;
+      int wbase = 0;
+      bool any = false;
+      for (int i0 = 0; i0 < nitems; i0 += 64) {
+        const int i = i0 + lane;
+        const bool mine = i < nitems;
+        uint64_t A = 0, B = 0;
+        uint32_t M = 0, I = 0;
+        int cnt = 0, cards = 0;
+        if (mine) {
+          A = W.itA[cur][i]; B = W.itB[cur][i]; M = W.itM[cur][i]; I = W.itI[cur][i];
+          cnt = W.tcnt[i]; cards = W.tcards[i];
+        }
+        const bool leaf = (A | B) == 0;
+        bool expand = mine && !leaf && (marginal_partial ? cards > tau : cards >= tau);
+        if (marginal_partial) {  // members of the marginal class, in order, while their growth still fits
+          const bool cand = mine && !leaf && cards == tau;
+          const int g = cand ? cnt - 1 : 0;
+          const int gin = wave_incl_scan(g, lane);
+          if (cand && gin <= mleft) expand = true;
+          // the prefix property: stop at the first member that does not fit
+          const uint64_t bad = __ballot(cand && gin > mleft);
+          if (bad) {
+            mleft = -1;  // nothing behind the first misfit expands any more (gin is non-decreasing: a prefix)
+          } else {
+            mleft -= (int)rl((uint32_t)gin, 63);
+          }
+        }
+        const int oc = mine ? (expand ? cnt : 1) : 0;
+        const int oin = wave_incl_scan(oc, lane);
+        int w = wbase + oin - oc;
+        wbase += (int)rl((uint32_t)oin, 63);
+        any = any || __ballot(expand) != 0;
+        if (mine) {
+          if (!expand) {
+            W.itA[nxt][w] = A; W.itB[nxt][w] = B; W.itM[nxt][w] = M; W.itI[nxt][w] = I;
+          } else {
+            const int sum2 = (int)(M & 1023) - 512, cvmin = (int)(int8_t)((M >> 10) & 0xFF), nact = (int)((M >> 18) & 31);
+            const int idmin = (int)(I & 0x3FFF);
+            auto put = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int fromc) {
+              int cv = cvmin, im = idmin;
+              if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cv = v2; im = id; }
+              W.itA[nxt][w] = A2; W.itB[nxt][w] = B2;
+              W.itM[nxt][w] = (uint32_t)((sum2 + v2 + 512) & 1023) | ((uint32_t)(cv & 0xFF) << 10) | ((uint32_t)(nact + 1) << 18);
+              W.itI[nxt][w] = (uint32_t)im | ((uint32_t)fromc << 14);
+              ++w;
+              ++nodes_l;
+            };
+            const int pr = pend_rank(A, B);
+            if (pr >= 0) {
+              put(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, A2_NOFROM);
+              if (pair_option(B, pr)) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM);
+            } else {
+              const int ul = a2_lowrank(A), from = (int)((I >> 14) & 1023);
+              const int lo = from != A2_NOFROM ? from : (int)W.bstart[ul], hi = (int)W.bstart[ul + 1];
+              for (int pp = lo; pp < hi; ++pp) {
+                const uint64_t nib = W.cn[pp];
+                if (!a2_fits(nib, A)) continue;
+                const uint32_t ci = W.ci[pp];
+                uint64_t A2, B2;
+                a2_child(q, A, B, nib, A2, B2);
+                const bool same = !q.nosplit && a2_lowrank(A2) == ul;  // <= 10 cards: the row index may not decrease
+                put(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), same ? pp : A2_NOFROM);
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!any) break;  // nothing fitted (or only finished combinations are left): the list in `cur` stands
+      nitems = wbase;
+      cur = nxt;
+    }
+
+#ifdef DDZ_STAMP
+    tq[2] = __builtin_amdgcn_s_memtime();
+    const int nitems_final = nitems;
+#endif
+    // ---- 3. search: lanes take items from the end of the list and walk their subtrees
+    AutoBest best{-__builtin_inf(), -1};
+    int best_key = 0x7FFFFFFF;
+    int next_item = nitems;  // wave-uniform: items [0, next_item) are not taken yet
+    bool act = false;
+    uint64_t A = 0, B = 0;
+    int d = 0, nact = 0, sum2 = 0, cvmin = AUTO_NONE, idmin = 0, key = 0;
+    int p = 0, hi = 0, opt = 3, pr = 0;  // opt: 3 = regular node (cursor p < hi), 0 / 1 / 2 = next solo option of rank pr
+    auto score_here = [&]() {
+      AutoBest b2{-__builtin_inf(), -1};
+      auto_leaf(b2, sum2, cvmin, idmin, nact, q.follow, q.pass_ok, q.rp);
+      ++combs_l;
+      // inside an item: first maximum (strict >); across items: the smaller item index wins a tie
+      if (b2.move >= 0 && (b2.value > best.value || (b2.value == best.value && key < best_key) || best.move < 0)) {
+        best = b2;
+        best_key = key;
+      }
+    };
+    auto open_node = [&](int from) {
+      const int r = pend_rank(A, B);
+      if (r >= 0) { opt = 0; pr = r; return; }
+      opt = 3;
+      const int ul = a2_lowrank(A);
+      p = from != A2_NOFROM ? from : (int)W.bstart[ul];
+      hi = (int)W.bstart[ul + 1];
+    };
+    auto backtrack = [&]() {
+      if (d == 0) { act = false; return; }
+      --d; --nact;
+      const uint32_t e = W.stack[d][lane];
+      const int code = (int)(e & 1023);
+      cvmin = (int)(int8_t)((e >> 10) & 0xFF);
+      idmin = (int)(e >> 18);
+      if (code < 512) {  // undo a regular action: back to its node, next candidate
+        const uint64_t nib = W.cn[code];
+        sum2 -= (int)(int8_t)((W.ci[code] >> 14) & 0xFF);
+        if (q.nosplit) {
+          const uint64_t rm = a2_rankmask(nib);
+          A = A | ((B & rm) + nib);
+          B = B & ~rm;
+        } else {
+          A = A + nib;
+        }
+        opt = 3; p = code + 1; hi = (int)W.bstart[a2_lowrank(A) + 1];
+      } else {           // undo a solo single / pair
+        pr = (code - 512) >> 1;
+        const int oi = (code - 512) & 1;
+        B += (uint64_t)(oi + 1) << (4 * pr);
+        sum2 -= oi ? a2_pair_v2(pr) : a2_single_v2(pr);
+        opt = oi + 1;
+      }
+    };
+    auto descend = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int code, int fromc) {
+      W.stack[d][lane] = (uint32_t)code | ((uint32_t)(cvmin & 0xFF) << 10) | ((uint32_t)idmin << 18);
+      ++d; ++nact; ++nodes_l;
+      sum2 += v2;
+      if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cvmin = v2; idmin = id; }
+      A = A2; B = B2;
+      if ((A | B) == 0) { score_here(); backtrack(); }
+      else open_node(fromc);
+    };
+    for (;;) {
+      // idle lanes take the next items
+      const uint64_t idle = __ballot(!act);
+      if (idle && next_item > 0) {
+        const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const int k = next_item - 1 - r;
+        if (!act && k >= 0) {
+          A = W.itA[cur][k]; B = W.itB[cur][k];
+          const uint32_t M = W.itM[cur][k], I = W.itI[cur][k];
+          sum2 = (int)(M & 1023) - 512; cvmin = (int)(int8_t)((M >> 10) & 0xFF); nact = (int)((M >> 18) & 31);
+          idmin = (int)(I & 0x3FFF);
+          key = k; d = 0;
+          if ((A | B) == 0) score_here();
+          else { act = true; open_node((int)((I >> 14) & 1023)); }
+        }
+        next_item -= __popcll(idle);
+        if (next_item < 0) next_item = 0;
+      }
+      if (__ballot(act) == 0) {
+        if (next_item <= 0) break;
+        continue;
+      }
+      if (act) {  // one candidate test, or one descend / backtrack
+        if (opt == 3) {
+          // next candidate of the bucket that fits what is left: four independent LDS reads per round (a bucket holds
+          // every action of the ORIGINAL hand with this lowest rank; deep in the tree few of them still fit)
+          uint64_t nib = 0;
+          bool found = false;
+          while (p < hi) {
+            const uint64_t n0 = W.cn[p], n1 = W.cn[p + 1 < hi ? p + 1 : p], n2 = W.cn[p + 2 < hi ? p + 2 : p],
+                           n3 = W.cn[p + 3 < hi ? p + 3 : p];
+            const uint32_t fm = (a2_fits(n0, A) ? 1u : 0u) | (p + 1 < hi && a2_fits(n1, A) ? 2u : 0u) |
+                                (p + 2 < hi && a2_fits(n2, A) ? 4u : 0u) | (p + 3 < hi && a2_fits(n3, A) ? 8u : 0u);
+            if (fm) {
+              const int o = __builtin_ctz(fm);
+              p += o;
+              nib = o == 0 ? n0 : o == 1 ? n1 : o == 2 ? n2 : n3;
+              found = true;
+              break;
+            }
+            p += 4;
+          }
+          if (found) {
+            const uint32_t ci = W.ci[p];
+            uint64_t A2, B2;
+            a2_child(q, A, B, nib, A2, B2);
+            const bool same = !q.nosplit && a2_lowrank(A2) == a2_lowrank(A);
+            descend(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), p, same ? p : A2_NOFROM);
+          } else {
+            backtrack();
+          }
+        } else if (opt == 0) {
+          descend(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, 512 + 2 * pr, A2_NOFROM);
+        } else if (opt == 1 && pair_option(B, pr)) {
+          descend(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, 512 + 2 * pr + 1, A2_NOFROM);
+        } else {
+          backtrack();
+        }
+      }
+    }
+#ifdef DDZ_STAMP
+    tq[3] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- 4. the wave's best: larger value, on ties the smaller item index
+    double bv = best.move >= 0 ? best.value : -__builtin_inf();
+    int bk = best.move >= 0 ? best_key : 0x7FFFFFFF, bm = best.move;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      const double ov = __shfl_xor(bv, s);
+      const int ok2 = __shfl_xor(bk, s), om = __shfl_xor(bm, s);
+      const bool take = om >= 0 && (bm < 0 || ov > bv || (ov == bv && ok2 < bk));
+      if (take) { bv = ov; bk = ok2; bm = om; }
+    }
+    const int nodes = wave_sum(nodes_l), combs = wave_sum(combs_l);
+    if (lane == 0) {
+      a.ids[t] = bm < 0 ? 0 : bm;  // rule_based_model.py:87-89
+      if (a.stats) { a.stats[2 * t] = combs; a.stats[2 * t + 1] = nodes; }
+    }
+#ifdef DDZ_STAMP
+    if (g_stamps && lane == 0) {
+      g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];
+      g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
+    }
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
+}

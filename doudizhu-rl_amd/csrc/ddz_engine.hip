@@ -513,13 +513,14 @@ __device__ __forceinline__ uint32_t last_info(uint64_t n1, int c1, uint64_t n2, 
   return mk_info(EMPTY, 0, 1);
 }
 
-#include "ddz_auto.h"
-
 // DDZ_STAMP: diagnostic build only (tools/stamp_probe.py): k_rollout accumulates s_memtime
 // deltas per phase into a debug buffer nothing else reads.
 #ifdef DDZ_STAMP
 __device__ unsigned long long* g_stamps = nullptr;  // [T][16]
 #endif
+#include "ddz_auto.h"
+#include "ddz_auto2.h"
+
 
 struct TableArgs {
   uint8_t* state;
@@ -1911,6 +1912,36 @@ int ensure_counts(ddz_env* e, hipStream_t st) {
 }
 }  // namespace
 
+namespace {
+// k_auto2 keeps ~150 KB of LDS per block: one block per CU, tables round-robin over the resident waves.
+// DDZ_AUTO_KERNEL=1 selects the sequential reference kernel k_auto (diagnostics; same results).
+static int auto_blocks(int device, int64_t n) {
+  static int cus[MAX_DEVICES] = {};
+  if (device >= 0 && device < MAX_DEVICES && cus[device] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+    cus[device] = v;
+  }
+  const int64_t want = (n + A2_WPB - 1) / A2_WPB;
+  const int64_t cap = device >= 0 && device < MAX_DEVICES ? cus[device] : 256;
+  return (int)(want < cap ? want : cap);
+}
+template <bool STATE>
+static int launch_auto(int device, const AutoArgs& a, hipStream_t st) {
+  if (env_int("DDZ_AUTO_KERNEL", 1, 2, 2) == 1)
+    hipLaunchKernelGGL(k_auto<STATE>, dim3((unsigned)((a.T + WPB - 1) / WPB)), dim3(TB), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_auto2<STATE>, dim3((unsigned)auto_blocks(device, a.T)), dim3(A2_TB), 0, st, a);
+  return check_launch();
+}
+
+static void fill_round_penalty(AutoArgs& a) {
+  // rule_based_model.py:57: round_penalty = 15 - 12 * min_oppo_cards / 20 (Python: int product, true division)
+  for (int m = 0; m < 24; ++m) a.rp[m] = 15 - 12 * m / 20.0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ddz_abi_version(void) { return DDZ_ABI_VERSION; }
@@ -2234,11 +2265,6 @@ int ddz_rollout_random_timed(ddz_env_t* e, int64_t n_iters, int32_t* counts, int
   return rc;
 }
 
-static void fill_round_penalty(AutoArgs& a) {
-  // rule_based_model.py:57: round_penalty = 15 - 12 * min_oppo_cards / 20 (Python: int product, true division)
-  for (int m = 0; m < 24; ++m) a.rp[m] = 15 - 12 * m / 20.0;
-}
-
 int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* stats, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!ids || !al(ids, 4) || !al(stats, 8) || auto_roles < 0 || auto_roles > 7) return DDZ_EINVAL;
@@ -2248,8 +2274,7 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
   a.status = e->sc.status;
   fill_round_penalty(a);
-  hipLaunchKernelGGL(k_auto<true>, dim3((unsigned)((e->T + WPB - 1) / WPB)), dim3(TB), 0, (hipStream_t)stream, a);
-  return check_launch();
+  return launch_auto<true>(e->device, a, (hipStream_t)stream);
 }
 
 int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n, int32_t* ids,
@@ -2264,8 +2289,7 @@ int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const 
   a.hands = (const uint4*)hands; a.lasts = (const uint4*)lasts; a.info = (const uint32_t*)info;
   a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = nullptr;
   fill_round_penalty(a);
-  hipLaunchKernelGGL(k_auto<false>, dim3((unsigned)((n + WPB - 1) / WPB)), dim3(TB), 0, (hipStream_t)stream, a);
-  return check_launch();
+  return launch_auto<false>(device, a, (hipStream_t)stream);
 }
 
 int ddz_debug_cards_value(int device, int8_t* out, void* stream) {

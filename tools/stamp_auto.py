@@ -1,0 +1,48 @@
+"""Diagnostic: -DDDZ_STAMP build, where do k_auto2's waves spend their cycles per decision (staging+sort / frontier / search)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "doudizhu-rl_amd", "csrc")
+out = os.path.join(ROOT, "build_variants")
+os.makedirs(out, exist_ok=True)
+lib = os.path.join(out, "stamp.so")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DDDZ_STAMP=1",
+                       "-o", lib, os.path.join(csrc, "ddz_engine.hip")])
+os.environ["DDZ_HIP_LIB"] = lib
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+pkg = importlib.import_module("doudizhu-rl_amd")
+raw = C.CDLL(lib)
+raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+env = pkg.BatchedEnv(T, seed=0)
+env.reset()
+env.legal_slab()
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+    env.step_auto(0b101, slab=True)
+buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
+assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+ids = env.auto_choose(0b101)
+e1.record()
+torch.cuda.synchronize()
+assert raw.ddz_debug_set_stamps(None) == 0
+s = buf.cpu().numpy().astype(np.float64)
+s = s[(ids.cpu().numpy() >= 0)]
+print(f"T={T}: {len(s)} decisions, launch {e0.elapsed_time(e1) * 1e3:.0f} us; cycles per decision (s_memtime)")
+for k, nm in enumerate(["staging + sort", "frontier passes", "search"]):
+    print(f"  {nm:18s} mean {s[:, k].mean():9.0f}  p50 {np.percentile(s[:, k], 50):9.0f}  p99 {np.percentile(s[:, k], 99):9.0f}  max {s[:, k].max():9.0f}")
+tot = s[:, :3].sum(1)
+print(f"  total              mean {tot.mean():9.0f}  p99 {np.percentile(tot, 99):9.0f}  max {tot.max():9.0f}   sum/1024 waves {tot.sum() / 1024:.0f}")
+print(f"  frontier items mean {s[:, 3].mean():.0f} max {s[:, 3].max():.0f}; nodes mean {s[:, 4].mean():.0f} max {s[:, 4].max():.0f}; candidates mean {s[:, 5].mean():.0f} max {s[:, 5].max():.0f}")
+heavy = np.argsort(-tot)[:5]
+for h in heavy:
+    print("   heavy:", [int(x) for x in s[h, :6]])
