@@ -19,10 +19,10 @@
 // Included by ddz_engine.hip after ddz_auto.h.
 #pragma once
 
-constexpr int A2_WPB = 4;       // waves per block (the frontier needs LDS: ~34 KB per wave)
+constexpr int A2_WPB = 8;       // waves per block (17 KB of LDS per wave + the shared record table)
 constexpr int A2_TB = A2_WPB * 64;
-constexpr int A2_CAP = 448;     // frontier items per table
-constexpr int A2_PASSES = 12;   // expansion passes at most
+constexpr int A2_CAP = 128;     // frontier items per table (slots 64.. of the spare buffer carry the keys of donations)
+constexpr int A2_PASSES = 6;    // expansion passes at most
 constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
 
@@ -68,11 +68,29 @@ __device__ __forceinline__ void a2_child(const A2Ctx& q, uint64_t A, uint64_t B,
     B2 = 0;
   }
 }
+// >= 0: the lowest uncovered slot is a surplus card of that touched rank; -1: a regular node
+__device__ __forceinline__ int a2_pend_rank(uint64_t A, uint64_t B) {
+  const int ul = a2_lowrank(A), pl = a2_lowrank(B);
+  return pl < ul ? pl : -1;
+}
+// the augmented pair of slots 2, 3 (card.py:544-547) is an option when two cards of a quad are pending
+__device__ __forceinline__ bool a2_pair_option(uint64_t hand, uint64_t B, int pr) {
+  return ((B >> (4 * pr)) & 15) == 2 && ((hand >> (4 * pr)) & 15) == 4;
+}
+// first position of rank r's bucket from three words of seven 9-bit entries (r = 15: the number of candidates).
+// Masks, not ?: on the words: a select by a small index is lowered to an indexed SCRATCH array (measured: the search
+// loop ran several times slower with one scratch access per node)
+__device__ __forceinline__ int a2_bs(uint64_t w0, uint64_t w1, uint64_t w2, int r) {
+  const uint64_t w = (w0 & (0ull - (uint64_t)(r < 7))) | (w1 & (0ull - (uint64_t)(r >= 7 && r < 14))) |
+                     (w2 & (0ull - (uint64_t)(r >= 14)));
+  const int k = r - 7 * (int)(r >= 7) - 7 * (int)(r >= 14);
+  return (int)((w >> (9 * k)) & 511u);
+}
 __device__ __forceinline__ int a2_single_v2(int r) { return 2 * (r - 7); }
 __device__ __forceinline__ int a2_pair_v2(int r) { return r - 7 > 0 ? 3 * (r - 7) : 2 * (r - 7); }
 
 template <bool STATE>
-__global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
+__global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
   __shared__ Auto2Wave s_w[A2_WPB];
   const int lane = threadIdx.x & 63;
@@ -202,15 +220,16 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
       }
     }
     __builtin_amdgcn_wave_barrier();
-
-    // ---- helpers on a node (A, B): the lowest uncovered slot decides its kind
-    auto pend_rank = [&](uint64_t A, uint64_t B) -> int {  // >= 0: a surplus card of that touched rank leaves next
-      const int ul = a2_lowrank(A), pl = a2_lowrank(B);
-      return pl < ul ? pl : -1;
-    };
-    auto pair_option = [&](uint64_t B, int pr) -> bool {     // augmented pair of slots 2, 3 (card.py:544-547)
-      return ((B >> (4 * pr)) & 15) == 2 && ((q.hand >> (4 * pr)) & 15) == 4;
-    };
+    // the bucket starts once more as three wave-uniform words of seven 9-bit entries: a lookup by a lane's own rank is
+    // a shift instead of an LDS round trip in the search loop
+    uint64_t bsw0 = 0, bsw1 = 0, bsw2 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint64_t v = (uint64_t)(rl((uint32_t)start_lane, r) & 511u);
+      if (r < 7) bsw0 |= v << (9 * r);
+      else if (r < 14) bsw1 |= v << (9 * (r - 7));
+      else bsw2 |= v << (9 * (r - 14));
+    }
 
 #ifdef DDZ_STAMP
     tq[1] = __builtin_amdgcn_s_memtime();
@@ -225,7 +244,9 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
       W.itI[0][0] = (uint32_t)A2_NOFROM << 14;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int pass = 0; pass < A2_PASSES; ++pass) {
+    // enough subtrees to feed 64 lanes; the heavy trees (many candidates) get the whole list for balance
+    const int target = 64;
+    for (int pass = 0; pass < A2_PASSES && nitems < target; ++pass) {
       // (a) children count and cards left of every item; extra slots wanted per cards-left class
       if (lane < 24) W.hist[lane] = 0;
       __builtin_amdgcn_wave_barrier();
@@ -237,12 +258,12 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
           int cnt = 1, cards = 0;  // a finished combination stays as it is
           if ((A | B) != 0) {
             cards = nib_sum(A) + nib_sum(B);
-            const int pr = pend_rank(A, B);
+            const int pr = a2_pend_rank(A, B);
             if (pr >= 0) {
-              cnt = 1 + (pair_option(B, pr) ? 1 : 0);
+              cnt = 1 + (a2_pair_option(q.hand, B, pr) ? 1 : 0);
             } else {
               const int ul = a2_lowrank(A), from = (int)((I >> 14) & 1023);
-              const int lo = from != A2_NOFROM ? from : (int)W.bstart[ul], hi = (int)W.bstart[ul + 1];
+              const int lo = from != A2_NOFROM ? from : a2_bs(bsw0, bsw1, bsw2, ul), hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
               cnt = 0;
               for (int p = lo; p < hi; ++p) cnt += a2_fits(W.cn[p], A) ? 1 : 0;
             }
@@ -314,13 +335,13 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
               ++w;
               ++nodes_l;
             };
-            const int pr = pend_rank(A, B);
+            const int pr = a2_pend_rank(A, B);
             if (pr >= 0) {
               put(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, A2_NOFROM);
-              if (pair_option(B, pr)) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM);
+              if (a2_pair_option(q.hand, B, pr)) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM);
             } else {
               const int ul = a2_lowrank(A), from = (int)((I >> 14) & 1023);
-              const int lo = from != A2_NOFROM ? from : (int)W.bstart[ul], hi = (int)W.bstart[ul + 1];
+              const int lo = from != A2_NOFROM ? from : a2_bs(bsw0, bsw1, bsw2, ul), hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
               for (int pp = lo; pp < hi; ++pp) {
                 const uint64_t nib = W.cn[pp];
                 if (!a2_fits(nib, A)) continue;
@@ -344,137 +365,220 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
     tq[2] = __builtin_amdgcn_s_memtime();
     const int nitems_final = nitems;
 #endif
-    // ---- 3. search: lanes take items from the end of the list and walk their subtrees
+    // ---- 3. search: lanes take items from the end of the list and walk their subtrees; when the list is empty, idle
+    // lanes take over ALL unexplored siblings of a busy lane's SHALLOWEST open level (every shallower level of that lane is
+    // exhausted, so what it keeps -- the subtree of its current child at that level -- precedes the donated siblings in
+    // depth-first order; the taker descends into the first of them and its other siblings can be taken over in turn).
+    // Order keys are intervals: item k starts with [k << 40, (k + 1) << 40), a donation halves the donor's interval;
+    // combinations are scored under the lower end of their lane's interval.
     AutoBest best{-__builtin_inf(), -1};
-    int best_key = 0x7FFFFFFF;
+    uint64_t best_key = ~0ull;
     int next_item = nitems;  // wave-uniform: items [0, next_item) are not taken yet
     bool act = false;
-    uint64_t A = 0, B = 0;
-    int d = 0, nact = 0, sum2 = 0, cvmin = AUTO_NONE, idmin = 0, key = 0;
+    uint64_t A = 0, B = 0, A0 = 0, B0 = 0, klo = 0, khi = 0;
+    int d = 0, nact = 0, sum2 = 0, cvmin = AUTO_NONE, idmin = 0, sum0 = 0, n0 = 0;
     int p = 0, hi = 0, opt = 3, pr = 0;  // opt: 3 = regular node (cursor p < hi), 0 / 1 / 2 = next solo option of rank pr
-    auto score_here = [&]() {
-      AutoBest b2{-__builtin_inf(), -1};
-      auto_leaf(b2, sum2, cvmin, idmin, nact, q.follow, q.pass_ok, q.rp);
-      ++combs_l;
-      // inside an item: first maximum (strict >); across items: the smaller item index wins a tie
-      if (b2.move >= 0 && (b2.value > best.value || (b2.value == best.value && key < best_key) || best.move < 0)) {
-        best = b2;
-        best_key = key;
-      }
-    };
-    auto open_node = [&](int from) {
-      const int r = pend_rank(A, B);
-      if (r >= 0) { opt = 0; pr = r; return; }
-      opt = 3;
-      const int ul = a2_lowrank(A);
-      p = from != A2_NOFROM ? from : (int)W.bstart[ul];
-      hi = (int)W.bstart[ul + 1];
-    };
-    auto backtrack = [&]() {
-      if (d == 0) { act = false; return; }
-      --d; --nact;
-      const uint32_t e = W.stack[d][lane];
-      const int code = (int)(e & 1023);
-      cvmin = (int)(int8_t)((e >> 10) & 0xFF);
-      idmin = (int)(e >> 18);
-      if (code < 512) {  // undo a regular action: back to its node, next candidate
-        const uint64_t nib = W.cn[code];
-        sum2 -= (int)(int8_t)((W.ci[code] >> 14) & 0xFF);
-        if (q.nosplit) {
-          const uint64_t rm = a2_rankmask(nib);
-          A = A | ((B & rm) + nib);
-          B = B & ~rm;
-        } else {
-          A = A + nib;
-        }
-        opt = 3; p = code + 1; hi = (int)W.bstart[a2_lowrank(A) + 1];
-      } else {           // undo a solo single / pair
-        pr = (code - 512) >> 1;
-        const int oi = (code - 512) & 1;
-        B += (uint64_t)(oi + 1) << (4 * pr);
-        sum2 -= oi ? a2_pair_v2(pr) : a2_single_v2(pr);
-        opt = oi + 1;
-      }
-    };
-    auto descend = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int code, int fromc) {
-      W.stack[d][lane] = (uint32_t)code | ((uint32_t)(cvmin & 0xFF) << 10) | ((uint32_t)idmin << 18);
-      ++d; ++nact; ++nodes_l;
-      sum2 += v2;
-      if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cvmin = v2; idmin = id; }
-      A = A2; B = B2;
-      if ((A | B) == 0) { score_here(); backtrack(); }
-      else open_node(fromc);
-    };
+    uint32_t more = 0;                   // bit l: level l (a regular node the lane descended from) has positions left
+    uint32_t dead = 0;                   // bit l: the siblings of level l were given away: back there, the node is done
+#ifdef DDZ_STAMP
+    unsigned long long n_trips = 0, n_lane_trips = 0;
+#endif
+    const int mbox = cur ^ 1;            // the other item buffer is the mailbox of the donations
     for (;;) {
-      // idle lanes take the next items
-      const uint64_t idle = __ballot(!act);
-      if (idle && next_item > 0) {
+#ifdef DDZ_STAMP
+      n_trips += 1; n_lane_trips += __popcll(__ballot(act));
+#endif
+      bool want_score = false, want_open = false, want_back = false;
+      int open_from = A2_NOFROM;
+      uint64_t idle = __ballot(!act);
+      bool took = false;
+      uint32_t M = 0, I = 0;
+      if (idle && next_item > 0) {          // idle lanes take the next items of the list
         const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const int k = next_item - 1 - r;
         if (!act && k >= 0) {
-          A = W.itA[cur][k]; B = W.itB[cur][k];
-          const uint32_t M = W.itM[cur][k], I = W.itI[cur][k];
-          sum2 = (int)(M & 1023) - 512; cvmin = (int)(int8_t)((M >> 10) & 0xFF); nact = (int)((M >> 18) & 31);
-          idmin = (int)(I & 0x3FFF);
-          key = k; d = 0;
-          if ((A | B) == 0) score_here();
-          else { act = true; open_node((int)((I >> 14) & 1023)); }
+          A = W.itA[cur][k]; B = W.itB[cur][k]; M = W.itM[cur][k]; I = W.itI[cur][k];
+          klo = (uint64_t)k << 40; khi = (uint64_t)(k + 1) << 40;
+          took = true;
         }
         next_item -= __popcll(idle);
         if (next_item < 0) next_item = 0;
+      } else if (idle) {
+        const uint64_t busy = __ballot(act);
+        if (busy == 0) break;               // no lane works and no item is left
+        const uint64_t donors = __ballot(act && more != 0);
+        if (donors) {                       // idle lanes take over siblings of busy lanes
+          const int nd = __popcll(donors), nt = __popcll(idle), np = nd < nt ? nd : nt;
+          const int jd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+          if (act && more != 0 && jd < np) {
+            const int L = __builtin_ctz(more);
+            uint64_t a_ = A0, b_ = B0;      // replay the path down to level L
+            int s2 = sum0;
+            for (int l = 0; l < L; ++l) {
+              const int code = (int)(W.stack[l][lane] & 1023);
+              if (code < 512) {
+                uint64_t a2, b2;
+                a2_child(q, a_, b_, W.cn[code], a2, b2);
+                a_ = a2; b_ = b2;
+                s2 += (int)(int8_t)((W.ci[code] >> 14) & 0xFF);
+              } else {
+                const int r_ = (code - 512) >> 1, oi = (code - 512) & 1;
+                b_ -= (uint64_t)(oi + 1) << (4 * r_);
+                s2 += oi ? a2_pair_v2(r_) : a2_single_v2(r_);
+              }
+            }
+            const uint32_t e = W.stack[L][lane];
+            const int posL = (int)(e & 1023);  // a regular level: the child being explored; the taker starts behind it
+            const uint64_t kmid = klo + ((khi - klo) >> 1);
+            W.itA[mbox][jd] = a_; W.itB[mbox][jd] = b_;
+            W.itM[mbox][jd] = (uint32_t)((s2 + 512) & 1023) | (((e >> 10) & 0xFFu) << 10) | ((uint32_t)(n0 + L) << 18);
+            W.itI[mbox][jd] = (e >> 18) | ((uint32_t)(posL + 1) << 14);
+            W.itA[mbox][64 + jd] = kmid; W.itB[mbox][64 + jd] = khi;
+            khi = kmid;
+            more &= ~(1u << L);
+            dead |= 1u << L;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int jt = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+          if (!act && jt < np) {
+            A = W.itA[mbox][jt]; B = W.itB[mbox][jt]; M = W.itM[mbox][jt]; I = W.itI[mbox][jt];
+            klo = W.itA[mbox][64 + jt]; khi = W.itB[mbox][64 + jt];
+            took = true;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       }
-      if (__ballot(act) == 0) {
-        if (next_item <= 0) break;
-        continue;
+      if (took) {  // a fresh item: its root is level 0 of this lane's stack
+        sum2 = (int)(M & 1023) - 512; cvmin = (int)(int8_t)((M >> 10) & 0xFF); nact = (int)((M >> 18) & 31);
+        idmin = (int)(I & 0x3FFF);
+        d = 0; more = 0; dead = 0;
+        A0 = A; B0 = B; sum0 = sum2; n0 = nact;
+        if ((A | B) == 0) { want_score = true; }
+        else { act = true; want_open = true; open_from = (int)((I >> 14) & 1023); }
       }
-      if (act) {  // one candidate test, or one descend / backtrack
+      if (act && !want_open) {  // one step: the next child of this node, or back to the parent
+        bool desc = false;
+        uint64_t A2 = 0, B2 = 0;
+        int v2 = 0, id = 0, code = 0, fromc = A2_NOFROM;
+        bool el = false;
         if (opt == 3) {
           // next candidate of the bucket that fits what is left: four independent LDS reads per round (a bucket holds
           // every action of the ORIGINAL hand with this lowest rank; deep in the tree few of them still fit)
-          uint64_t nib = 0;
           bool found = false;
           while (p < hi) {
-            const uint64_t n0 = W.cn[p], n1 = W.cn[p + 1 < hi ? p + 1 : p], n2 = W.cn[p + 2 < hi ? p + 2 : p],
+            const uint64_t n0_ = W.cn[p], n1 = W.cn[p + 1 < hi ? p + 1 : p], n2 = W.cn[p + 2 < hi ? p + 2 : p],
                            n3 = W.cn[p + 3 < hi ? p + 3 : p];
-            const uint32_t fm = (a2_fits(n0, A) ? 1u : 0u) | (p + 1 < hi && a2_fits(n1, A) ? 2u : 0u) |
+            const uint32_t fm = (a2_fits(n0_, A) ? 1u : 0u) | (p + 1 < hi && a2_fits(n1, A) ? 2u : 0u) |
                                 (p + 2 < hi && a2_fits(n2, A) ? 4u : 0u) | (p + 3 < hi && a2_fits(n3, A) ? 8u : 0u);
             if (fm) {
-              const int o = __builtin_ctz(fm);
-              p += o;
-              nib = o == 0 ? n0 : o == 1 ? n1 : o == 2 ? n2 : n3;
+              p += __builtin_ctz(fm);
               found = true;
               break;
             }
             p += 4;
           }
           if (found) {
+            const uint64_t nib = W.cn[p];  // read again rather than select among the four by index (a scratch array)
             const uint32_t ci = W.ci[p];
-            uint64_t A2, B2;
             a2_child(q, A, B, nib, A2, B2);
             const bool same = !q.nosplit && a2_lowrank(A2) == a2_lowrank(A);
-            descend(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), p, same ? p : A2_NOFROM);
+            v2 = (int)(int8_t)((ci >> 14) & 0xFF); el = (ci >> 22) & 1u; id = (int)(ci & 0x3FFF);
+            code = p; fromc = same ? p : A2_NOFROM;
+            more = (more & ~(1u << d)) | ((p + 1 < hi ? 1u : 0u) << d);
+            desc = true;
           } else {
-            backtrack();
+            want_back = true;
           }
         } else if (opt == 0) {
-          descend(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, 512 + 2 * pr, A2_NOFROM);
-        } else if (opt == 1 && pair_option(B, pr)) {
-          descend(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, 512 + 2 * pr + 1, A2_NOFROM);
+          A2 = A; B2 = B - (1ull << (4 * pr));
+          v2 = a2_single_v2(pr); el = (q.esingle >> pr) & 1u; id = 1 + pr; code = 512 + 2 * pr;
+          more &= ~(1u << d);
+          desc = true;
+        } else if (opt == 1 && a2_pair_option(q.hand, B, pr)) {
+          A2 = A; B2 = B - (2ull << (4 * pr));
+          v2 = a2_pair_v2(pr); el = (q.epair >> pr) & 1u; id = 16 + pr; code = 512 + 2 * pr + 1;
+          more &= ~(1u << d);
+          desc = true;
         } else {
-          backtrack();
+          want_back = true;
+        }
+        if (desc) {
+          W.stack[d][lane] = (uint32_t)code | ((uint32_t)(cvmin & 0xFF) << 10) | ((uint32_t)idmin << 18);
+          ++d; ++nact; ++nodes_l;
+          sum2 += v2;
+          if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cvmin = v2; idmin = id; }
+          A = A2; B = B2;
+          if ((A | B) == 0) { want_score = true; want_back = true; }
+          else { want_open = true; open_from = fromc; }
+        }
+      }
+      if (want_score) {  // a finished combination
+        AutoBest b2{-__builtin_inf(), -1};
+        auto_leaf(b2, sum2, cvmin, idmin, nact, q.follow, q.pass_ok, q.rp);
+        ++combs_l;
+        // under one key: first maximum (strict >); otherwise the smaller key (earlier in depth-first order) wins a tie
+        if (b2.move >= 0 && (best.move < 0 || b2.value > best.value || (b2.value == best.value && klo < best_key))) {
+          best = b2;
+          best_key = klo;
+        }
+      }
+      if (want_open) {  // cursor of a fresh node
+        const int r = a2_pend_rank(A, B);
+        if (r >= 0) {
+          opt = 0; pr = r;
+        } else {
+          opt = 3;
+          const int ul = a2_lowrank(A);
+          p = open_from != A2_NOFROM ? open_from : a2_bs(bsw0, bsw1, bsw2, ul);
+          hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
+        }
+      }
+      if (want_back && act) {  // undo the last action of the path: back at its node, behind that child
+        if (d == 0) {
+          act = false; more = 0; dead = 0;
+        } else {
+          --d; --nact;
+          more &= (1u << d) - 1u;             // only levels the lane is BELOW can be given away
+          const bool gone = (dead >> d) & 1u; // the rest of this level was given away
+          dead &= (1u << d) - 1u;
+          const uint32_t e = W.stack[d][lane];
+          const int code = (int)(e & 1023);
+          cvmin = (int)(int8_t)((e >> 10) & 0xFF);
+          idmin = (int)(e >> 18);
+          if (code < 512) {
+            const uint64_t nib = W.cn[code];
+            sum2 -= (int)(int8_t)((W.ci[code] >> 14) & 0xFF);
+            if (q.nosplit) {
+              const uint64_t rm = a2_rankmask(nib);
+              A = A | ((B & rm) + nib);
+              B = B & ~rm;
+            } else {
+              A = A + nib;
+            }
+            opt = 3; p = code + 1;
+            hi = gone ? p : a2_bs(bsw0, bsw1, bsw2, a2_lowrank(A) + 1);
+          } else {
+            pr = (code - 512) >> 1;
+            const int oi = (code - 512) & 1;
+            B += (uint64_t)(oi + 1) << (4 * pr);
+            sum2 -= oi ? a2_pair_v2(pr) : a2_single_v2(pr);
+            opt = oi + 1;
+          }
         }
       }
     }
 #ifdef DDZ_STAMP
     tq[3] = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- 4. the wave's best: larger value, on ties the smaller item index
+    // ---- 4. the wave's best: larger value, on ties the smaller order key
     double bv = best.move >= 0 ? best.value : -__builtin_inf();
-    int bk = best.move >= 0 ? best_key : 0x7FFFFFFF, bm = best.move;
+    uint64_t bk = best.move >= 0 ? best_key : ~0ull;
+    int bm = best.move;
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-      const double ov = __shfl_xor(bv, s);
-      const int ok2 = __shfl_xor(bk, s), om = __shfl_xor(bm, s);
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const double ov = __shfl_xor(bv, sft);
+      const uint64_t ok2 = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(bk >> 32), sft) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)bk, sft);
+      const int om = __shfl_xor(bm, sft);
       const bool take = om >= 0 && (bm < 0 || ov > bv || (ov == bv && ok2 < bk));
       if (take) { bv = ov; bk = ok2; bm = om; }
     }
@@ -487,6 +591,7 @@ __global__ __launch_bounds__(A2_TB, 1) void k_auto2(AutoArgs a) {
     if (g_stamps && lane == 0) {
       g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];
       g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
+      g_stamps[16 * t + 6] = n_trips; g_stamps[16 * t + 7] = n_lane_trips;
     }
 #endif
     __builtin_amdgcn_wave_barrier();
