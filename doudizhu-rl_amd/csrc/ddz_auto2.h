@@ -25,6 +25,9 @@ constexpr int A2_CAP = 128;     // frontier items per table (slots 64.. of the s
 constexpr int A2_PASSES = 6;    // expansion passes at most
 constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
+#ifndef A2_SCAN_ROUNDS
+#define A2_SCAN_ROUNDS 1          // candidate-scan rounds (of four candidates) per search-loop trip
+#endif
 
 struct Auto2Wave {              // per wave
   uint64_t cn[STAGE_CAP];       // candidates: nibble-packed counts (during staging: nib | category << 60, unsorted)
@@ -55,7 +58,8 @@ __device__ __forceinline__ bool a2_fits(uint64_t nib, uint64_t a) {
 __device__ __forceinline__ uint64_t a2_rankmask(uint64_t nib) {  // 0xF on every rank the action touches
   uint64_t tm = nib | (nib >> 1);
   tm |= tm >> 2;
-  return (tm & ONES) * 15ull;
+  tm &= ONES;
+  return (tm << 4) - tm;  // x 15 without a 64-bit multiply
 }
 // child of a regular node after playing candidate `nib`
 __device__ __forceinline__ void a2_child(const A2Ctx& q, uint64_t A, uint64_t B, uint64_t nib, uint64_t& A2, uint64_t& B2) {
@@ -381,12 +385,16 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     uint32_t more = 0;                   // bit l: level l (a regular node the lane descended from) has positions left
     uint32_t dead = 0;                   // bit l: the siblings of level l were given away: back there, the node is done
 #ifdef DDZ_STAMP
-    unsigned long long n_trips = 0, n_lane_trips = 0;
+    unsigned long long n_trips = 0, n_lane_trips = 0, tsec[6] = {0, 0, 0, 0, 0, 0};
 #endif
     const int mbox = cur ^ 1;            // the other item buffer is the mailbox of the donations
-    for (;;) {
+    for (unsigned trip = 0;; ++trip) {
 #ifdef DDZ_STAMP
       n_trips += 1; n_lane_trips += __popcll(__ballot(act));
+      unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#define A2T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tsec[k] += n_ - ts0; ts0 = n_; } while (0)
+#else
+#define A2T(k) do { } while (0)
 #endif
       bool want_score = false, want_open = false, want_back = false;
       int open_from = A2_NOFROM;
@@ -406,7 +414,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       } else if (idle) {
         const uint64_t busy = __ballot(act);
         if (busy == 0) break;               // no lane works and no item is left
-        const uint64_t donors = __ballot(act && more != 0);
+        // a donation round costs about a trip: hold it when a quarter of the lanes idle, or every eighth trip
+        const bool round = __popcll(idle) >= 16 || (trip & 7) == 0;
+        const uint64_t donors = round ? __ballot(act && more != 0) : 0ull;
         if (donors) {                       // idle lanes take over siblings of busy lanes
           const int nd = __popcll(donors), nt = __popcll(idle), np = nd < nt ? nd : nt;
           const int jd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
@@ -448,6 +458,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           __builtin_amdgcn_wave_barrier();
         }
       }
+      A2T(0);
       if (took) {  // a fresh item: its root is level 0 of this lane's stack
         sum2 = (int)(M & 1023) - 512; cvmin = (int)(int8_t)((M >> 10) & 0xFF); nact = (int)((M >> 18) & 31);
         idmin = (int)(I & 0x3FFF);
@@ -465,12 +476,18 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           // next candidate of the bucket that fits what is left: four independent LDS reads per round (a bucket holds
           // every action of the ORIGINAL hand with this lowest rank; deep in the tree few of them still fit)
           bool found = false;
-          while (p < hi) {
+          uint64_t fnib = 0;
+          int rounds = A2_SCAN_ROUNDS;  // bounded per trip: a long bucket must not hold the other 63 lanes
+          while (p < hi && rounds-- > 0) {
             const uint64_t n0_ = W.cn[p], n1 = W.cn[p + 1 < hi ? p + 1 : p], n2 = W.cn[p + 2 < hi ? p + 2 : p],
                            n3 = W.cn[p + 3 < hi ? p + 3 : p];
             const uint32_t fm = (a2_fits(n0_, A) ? 1u : 0u) | (p + 1 < hi && a2_fits(n1, A) ? 2u : 0u) |
                                 (p + 2 < hi && a2_fits(n2, A) ? 4u : 0u) | (p + 3 < hi && a2_fits(n3, A) ? 8u : 0u);
             if (fm) {
+              // the first fit of the four, selected with masks (a select by index would become a scratch array)
+              const uint32_t lowbit = fm & (0u - fm);
+              fnib = (n0_ & (0ull - (uint64_t)(lowbit == 1u))) | (n1 & (0ull - (uint64_t)(lowbit == 2u))) |
+                     (n2 & (0ull - (uint64_t)(lowbit == 4u))) | (n3 & (0ull - (uint64_t)(lowbit == 8u)));
               p += __builtin_ctz(fm);
               found = true;
               break;
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             p += 4;
           }
           if (found) {
-            const uint64_t nib = W.cn[p];  // read again rather than select among the four by index (a scratch array)
+            const uint64_t nib = fnib;
             const uint32_t ci = W.ci[p];
             a2_child(q, A, B, nib, A2, B2);
             const bool same = !q.nosplit && a2_lowrank(A2) == a2_lowrank(A);
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             code = p; fromc = same ? p : A2_NOFROM;
             more = (more & ~(1u << d)) | ((p + 1 < hi ? 1u : 0u) << d);
             desc = true;
-          } else {
+          } else if (p >= hi) {
             want_back = true;
           }
         } else if (opt == 0) {
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           else { want_open = true; open_from = fromc; }
         }
       }
+      A2T(1);
       if (want_score) {  // a finished combination
         AutoBest b2{-__builtin_inf(), -1};
         auto_leaf(b2, sum2, cvmin, idmin, nact, q.follow, q.pass_ok, q.rp);
@@ -522,6 +540,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           best_key = klo;
         }
       }
+      A2T(2);
       if (want_open) {  // cursor of a fresh node
         const int r = a2_pend_rank(A, B);
         if (r >= 0) {
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
         }
       }
+      A2T(3);
       if (want_back && act) {  // undo the last action of the path: back at its node, behind that child
         if (d == 0) {
           act = false; more = 0; dead = 0;
@@ -566,6 +586,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           }
         }
       }
+      A2T(4);
     }
 #ifdef DDZ_STAMP
     tq[3] = __builtin_amdgcn_s_memtime();
@@ -592,6 +613,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];
       g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
       g_stamps[16 * t + 6] = n_trips; g_stamps[16 * t + 7] = n_lane_trips;
+      for (int k_ = 0; k_ < 5; ++k_) g_stamps[16 * t + 8 + k_] = tsec[k_];
     }
 #endif
     __builtin_amdgcn_wave_barrier();

@@ -44,6 +44,9 @@ tot = s[:, :3].sum(1)
 print(f"  total              mean {tot.mean():9.0f}  p99 {np.percentile(tot, 99):9.0f}  max {tot.max():9.0f}   sum/1024 waves {tot.sum() / 1024:.0f}")
 print(f"  frontier items mean {s[:, 3].mean():.0f} max {s[:, 3].max():.0f}; nodes mean {s[:, 4].mean():.0f} max {s[:, 4].max():.0f}; candidates mean {s[:, 5].mean():.0f} max {s[:, 5].max():.0f}")
 print(f"  search loop: trips mean {s[:, 6].mean():.0f} max {s[:, 6].max():.0f}; cycles per trip {s[:, 2].sum() / s[:, 6].sum():.0f}; active lanes per trip {s[:, 7].sum() / s[:, 6].sum():.1f}")
+names = ["take items / donations", "step (scan, descend)", "score", "open node", "backtrack"]
+for k, nm in enumerate(names):
+    print(f"    per trip: {nm:24s} {s[:, 8 + k].sum() / s[:, 6].sum():7.0f} cycles")
 heavy = np.argsort(-tot)[:5]
 for h in heavy:
     print("   heavy:", [int(x) for x in s[h, :8]])
