@@ -109,6 +109,11 @@ def other_config_legs(pkg, torch, dev):
     out["tables_65536_policy_loop_slab"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
                                             "us_per_iteration": dt / (20 * reps) * 1e6,
                                             "loop": "observe(EnvCooperationSimplify) + select_slab(random q) + step_slab(CHOICE)"}
+    # the same iteration in ONE launch: arg-max over q, apply, new lists and the new `face` (ddz_policy_step_slab)
+    dt, reps = timed_loop(lambda: [env.policy_step_slab(q, 0.0, face_variant=3, face_out=face) for _ in range(20)], sync)
+    out["tables_65536_policy_loop_fused"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
+                                             "us_per_iteration": dt / (20 * reps) * 1e6,
+                                             "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
     dt, reps = timed_loop(lambda: [env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True) for _ in range(20)], sync)
     out["tables_65536_step_slab_only"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6}
     # (3) configs[3]: farmers played by the rule-based opponent (Env.step_auto), the lord by the random policy

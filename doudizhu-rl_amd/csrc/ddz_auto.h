@@ -212,6 +212,8 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
         const bool el = !follow || auto_beats(cat, val, len, f);
         svl[j] = (uint16_t)((v2 & 0xFF) | (el ? 0x100 : 0));
         lr = __builtin_ctzll(nib) >> 2;
+        // the rule agent works on card.py's 13,527 rows in every build: a joker-kicker extra gets a row that never fits
+        if (DDZ_NATIVE_JOKER_KICKERS && sid[j] >= DDZ_NUM_ACTIONS) { stage[j] = NIBM | (e & ~NIBM); lr = 0; }
       }
 #pragma unroll
       for (int r = 0; r < 15; ++r) {

@@ -21,7 +21,8 @@
 
 constexpr int A2_WPB = 8;       // waves per block (17 KB of LDS per wave + the shared record table)
 constexpr int A2_TB = A2_WPB * 64;
-constexpr int A2_CAP = 128;     // frontier items per table (slots 64.. of the spare buffer carry the keys of donations)
+constexpr int A2_CAP = 96;      // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
+constexpr int A2_KEYLEVELS = 7; // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
 constexpr int A2_PASSES = 6;    // expansion passes at most
 constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
@@ -36,6 +37,7 @@ struct Auto2Wave {              // per wave
   uint64_t itB[2][A2_CAP];      //   pending surplus of the touched ranks (> 10 cards)
   uint32_t itM[2][A2_CAP];      //   (sum2 + 512) | (cvmin & 0xFF) << 10 | actions so far << 18
   uint32_t itI[2][A2_CAP];      //   idmin | first allowed position << 14 (A2_NOFROM = bucket start)
+  uint64_t itK[2][A2_CAP];      //   order key: the path of the node (and the cursor of a donated item) as 9-bit digits
   uint32_t stack[A2_DEPTH][64]; // per lane: code | (cvmin & 0xFF) << 10 | idmin << 18 of the level's parent
   int32_t hist[24];             // frontier pass: extra slots wanted by the items with c cards left
   uint16_t tcnt[A2_CAP];        //   children of item i
@@ -90,6 +92,11 @@ __device__ __forceinline__ int a2_bs(uint64_t w0, uint64_t w1, uint64_t w2, int 
   const int k = r - 7 * (int)(r >= 7) - 7 * (int)(r >= 14);
   return (int)((w >> (9 * k)) & 511u);
 }
+// order keys: digit `dig` (1..511) of path level `lvl` (0 = the root's choice, most significant); deeper levels have none
+__device__ __forceinline__ uint64_t a2_keydigit(int lvl, int dig) {
+  return lvl < A2_KEYLEVELS ? (uint64_t)dig << (9 * (A2_KEYLEVELS - 1 - lvl)) : 0ull;
+}
+__device__ __forceinline__ int a2_code_digit(int code) { return code < 512 ? code + 1 : ((code - 512) & 1) + 1; }
 __device__ __forceinline__ int a2_single_v2(int r) { return 2 * (r - 7); }
 __device__ __forceinline__ int a2_pair_v2(int r) { return r - 7 > 0 ? 3 * (r - 7) : 2 * (r - 7); }
 
@@ -192,7 +199,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         const int cat = (int)(e >> 60), vl = svl[j], val = vl & 0xFF, len = vl >> 8;
         const int v2 = auto_val2(nib, cat, val, len);
         const bool el = !q.follow || auto_beats(cat, val, len, f);
-        e_nib[u] = nib;
+        // the rule agent works on card.py's 13,527 rows in every build: the joker-kicker extras of the other rule set
+        // (ids >= 13527) get a row that never fits
+        e_nib[u] = (DDZ_NATIVE_JOKER_KICKERS && sid[j] >= DDZ_NUM_ACTIONS) ? NIBM : nib;
         e_ci[u] = (uint32_t)sid[j] | ((uint32_t)(v2 & 0xFF) << 14) | (el ? 1u << 22 : 0u);
         e_lr[u] = __builtin_ctzll(nib) >> 2;
       }
@@ -246,6 +255,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       W.itA[0][0] = hand; W.itB[0][0] = 0;
       W.itM[0][0] = 512u | ((uint32_t)(AUTO_NONE & 0xFF) << 10);
       W.itI[0][0] = (uint32_t)A2_NOFROM << 14;
+      W.itK[0][0] = 0;
     }
     __builtin_amdgcn_wave_barrier();
     // enough subtrees to feed 64 lanes; the heavy trees (many candidates) get the whole list for balance
@@ -297,11 +307,11 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       for (int i0 = 0; i0 < nitems; i0 += 64) {
         const int i = i0 + lane;
         const bool mine = i < nitems;
-        uint64_t A = 0, B = 0;
+        uint64_t A = 0, B = 0, K = 0;
         uint32_t M = 0, I = 0;
         int cnt = 0, cards = 0;
         if (mine) {
-          A = W.itA[cur][i]; B = W.itB[cur][i]; M = W.itM[cur][i]; I = W.itI[cur][i];
+          A = W.itA[cur][i]; B = W.itB[cur][i]; M = W.itM[cur][i]; I = W.itI[cur][i]; K = W.itK[cur][i];
           cnt = W.tcnt[i]; cards = W.tcards[i];
         }
         const bool leaf = (A | B) == 0;
@@ -326,23 +336,24 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         any = any || __ballot(expand) != 0;
         if (mine) {
           if (!expand) {
-            W.itA[nxt][w] = A; W.itB[nxt][w] = B; W.itM[nxt][w] = M; W.itI[nxt][w] = I;
+            W.itA[nxt][w] = A; W.itB[nxt][w] = B; W.itM[nxt][w] = M; W.itI[nxt][w] = I; W.itK[nxt][w] = K;
           } else {
             const int sum2 = (int)(M & 1023) - 512, cvmin = (int)(int8_t)((M >> 10) & 0xFF), nact = (int)((M >> 18) & 31);
             const int idmin = (int)(I & 0x3FFF);
-            auto put = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int fromc) {
+            auto put = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int fromc, int dig) {
               int cv = cvmin, im = idmin;
               if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cv = v2; im = id; }
               W.itA[nxt][w] = A2; W.itB[nxt][w] = B2;
               W.itM[nxt][w] = (uint32_t)((sum2 + v2 + 512) & 1023) | ((uint32_t)(cv & 0xFF) << 10) | ((uint32_t)(nact + 1) << 18);
               W.itI[nxt][w] = (uint32_t)im | ((uint32_t)fromc << 14);
+              W.itK[nxt][w] = K | a2_keydigit(nact, dig);
               ++w;
               ++nodes_l;
             };
             const int pr = a2_pend_rank(A, B);
             if (pr >= 0) {
-              put(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, A2_NOFROM);
-              if (a2_pair_option(q.hand, B, pr)) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM);
+              put(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, A2_NOFROM, 1);
+              if (a2_pair_option(q.hand, B, pr)) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM, 2);
             } else {
               const int ul = a2_lowrank(A), from = (int)((I >> 14) & 1023);
               const int lo = from != A2_NOFROM ? from : a2_bs(bsw0, bsw1, bsw2, ul), hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
                 uint64_t A2, B2;
                 a2_child(q, A, B, nib, A2, B2);
                 const bool same = !q.nosplit && a2_lowrank(A2) == ul;  // <= 10 cards: the row index may not decrease
-                put(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), same ? pp : A2_NOFROM);
+                put(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), same ? pp : A2_NOFROM, pp + 1);
               }
             }
           }
@@ -373,17 +384,21 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     // lanes take over ALL unexplored siblings of a busy lane's SHALLOWEST open level (every shallower level of that lane is
     // exhausted, so what it keeps -- the subtree of its current child at that level -- precedes the donated siblings in
     // depth-first order; the taker descends into the first of them and its other siblings can be taken over in turn).
-    // Order keys are intervals: item k starts with [k << 40, (k + 1) << 40), a donation halves the donor's interval;
-    // combinations are scored under the lower end of their lane's interval.
+    // Order keys are paths: seven 9-bit digits, digit l = (position of the child chosen at level l) + 1 (solo single 1,
+    // solo pair 2), 0 beyond the item's root; a given-away item (node, cursor) carries the cursor's digit at the node's
+    // level.  Depth-first order of the items = numeric order of the keys; combinations are scored under their item's key;
+    // levels below the seventh cannot be given away.
     AutoBest best{-__builtin_inf(), -1};
     uint64_t best_key = ~0ull;
     int next_item = nitems;  // wave-uniform: items [0, next_item) are not taken yet
     bool act = false;
-    uint64_t A = 0, B = 0, A0 = 0, B0 = 0, klo = 0, khi = 0;
+    uint64_t A = 0, B = 0, A0 = 0, B0 = 0, klo = 0;
     int d = 0, nact = 0, sum2 = 0, cvmin = AUTO_NONE, idmin = 0, sum0 = 0, n0 = 0;
     int p = 0, hi = 0, opt = 3, pr = 0;  // opt: 3 = regular node (cursor p < hi), 0 / 1 / 2 = next solo option of rank pr
     uint32_t more = 0;                   // bit l: level l (a regular node the lane descended from) has positions left
     uint32_t dead = 0;                   // bit l: the siblings of level l were given away: back there, the node is done
+    uint32_t pendopen = 0;               // bit l: level l is a solo-single choice whose solo-pair alternative is still to come:
+                                         //        nothing BELOW it may be given away (it would precede that alternative)
 #ifdef DDZ_STAMP
     unsigned long long n_trips = 0, n_lane_trips = 0, tsec[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -405,8 +420,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const int k = next_item - 1 - r;
         if (!act && k >= 0) {
-          A = W.itA[cur][k]; B = W.itB[cur][k]; M = W.itM[cur][k]; I = W.itI[cur][k];
-          klo = (uint64_t)k << 40; khi = (uint64_t)(k + 1) << 40;
+          A = W.itA[cur][k]; B = W.itB[cur][k]; M = W.itM[cur][k]; I = W.itI[cur][k]; klo = W.itK[cur][k];
           took = true;
         }
         next_item -= __popcll(idle);
@@ -416,16 +430,21 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         if (busy == 0) break;               // no lane works and no item is left
         // a donation round costs about a trip: hold it when a quarter of the lanes idle, or every eighth trip
         const bool round = __popcll(idle) >= 16 || (trip & 7) == 0;
-        const uint64_t donors = round ? __ballot(act && more != 0) : 0ull;
+        const bool can_give = act && more != 0 && (more & (0u - more)) < ((pendopen & (0u - pendopen)) | 0x80000000u) &&
+                              n0 + __builtin_ctz(more | 0x80000000u) < A2_KEYLEVELS;  // the given level must have a key digit
+        const uint64_t donors = round ? __ballot(can_give) : 0ull;
         if (donors) {                       // idle lanes take over siblings of busy lanes
           const int nd = __popcll(donors), nt = __popcll(idle), np = nd < nt ? nd : nt;
           const int jd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
-          if (act && more != 0 && jd < np) {
+          if (can_give && jd < np) {
             const int L = __builtin_ctz(more);
             uint64_t a_ = A0, b_ = B0;      // replay the path down to level L
             int s2 = sum0;
+            // key of the node at level L: this item's key up to its root, then the digits of the path below the root
+            uint64_t kk = n0 > 0 ? klo & ~((1ull << (9 * (A2_KEYLEVELS - n0))) - 1ull) : 0ull;
             for (int l = 0; l < L; ++l) {
               const int code = (int)(W.stack[l][lane] & 1023);
+              kk |= a2_keydigit(n0 + l, a2_code_digit(code));
               if (code < 512) {
                 uint64_t a2, b2;
                 a2_child(q, a_, b_, W.cn[code], a2, b2);
@@ -439,12 +458,10 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             }
             const uint32_t e = W.stack[L][lane];
             const int posL = (int)(e & 1023);  // a regular level: the child being explored; the taker starts behind it
-            const uint64_t kmid = klo + ((khi - klo) >> 1);
             W.itA[mbox][jd] = a_; W.itB[mbox][jd] = b_;
             W.itM[mbox][jd] = (uint32_t)((s2 + 512) & 1023) | (((e >> 10) & 0xFFu) << 10) | ((uint32_t)(n0 + L) << 18);
             W.itI[mbox][jd] = (e >> 18) | ((uint32_t)(posL + 1) << 14);
-            W.itA[mbox][64 + jd] = kmid; W.itB[mbox][64 + jd] = khi;
-            khi = kmid;
+            W.itK[mbox][jd] = kk | a2_keydigit(n0 + L, posL + 2);  // digit of position posL + 1: everything from there on
             more &= ~(1u << L);
             dead |= 1u << L;
           }
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           const int jt = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
           if (!act && jt < np) {
             A = W.itA[mbox][jt]; B = W.itB[mbox][jt]; M = W.itM[mbox][jt]; I = W.itI[mbox][jt];
-            klo = W.itA[mbox][64 + jt]; khi = W.itB[mbox][64 + jt];
+            klo = W.itK[mbox][jt];
             took = true;
           }
           __builtin_amdgcn_wave_barrier();
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       if (took) {  // a fresh item: its root is level 0 of this lane's stack
         sum2 = (int)(M & 1023) - 512; cvmin = (int)(int8_t)((M >> 10) & 0xFF); nact = (int)((M >> 18) & 31);
         idmin = (int)(I & 0x3FFF);
-        d = 0; more = 0; dead = 0;
+        d = 0; more = 0; dead = 0; pendopen = 0;
         A0 = A; B0 = B; sum0 = sum2; n0 = nact;
         if ((A | B) == 0) { want_score = true; }
         else { act = true; want_open = true; open_from = (int)((I >> 14) & 1023); }
@@ -502,6 +519,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             v2 = (int)(int8_t)((ci >> 14) & 0xFF); el = (ci >> 22) & 1u; id = (int)(ci & 0x3FFF);
             code = p; fromc = same ? p : A2_NOFROM;
             more = (more & ~(1u << d)) | ((p + 1 < hi ? 1u : 0u) << d);
+            pendopen &= ~(1u << d);
             desc = true;
           } else if (p >= hi) {
             want_back = true;
@@ -510,11 +528,13 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           A2 = A; B2 = B - (1ull << (4 * pr));
           v2 = a2_single_v2(pr); el = (q.esingle >> pr) & 1u; id = 1 + pr; code = 512 + 2 * pr;
           more &= ~(1u << d);
+          pendopen = (pendopen & ~(1u << d)) | ((a2_pair_option(q.hand, B, pr) ? 1u : 0u) << d);
           desc = true;
         } else if (opt == 1 && a2_pair_option(q.hand, B, pr)) {
           A2 = A; B2 = B - (2ull << (4 * pr));
           v2 = a2_pair_v2(pr); el = (q.epair >> pr) & 1u; id = 16 + pr; code = 512 + 2 * pr + 1;
           more &= ~(1u << d);
+          pendopen &= ~(1u << d);
           desc = true;
         } else {
           want_back = true;
@@ -555,12 +575,13 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       A2T(3);
       if (want_back && act) {  // undo the last action of the path: back at its node, behind that child
         if (d == 0) {
-          act = false; more = 0; dead = 0;
+          act = false; more = 0; dead = 0; pendopen = 0;
         } else {
           --d; --nact;
           more &= (1u << d) - 1u;             // only levels the lane is BELOW can be given away
           const bool gone = (dead >> d) & 1u; // the rest of this level was given away
           dead &= (1u << d) - 1u;
+          pendopen &= (1u << d) - 1u;
           const uint32_t e = W.stack[d][lane];
           const int code = (int)(e & 1023);
           cvmin = (int)(int8_t)((e >> 10) & 0xFF);

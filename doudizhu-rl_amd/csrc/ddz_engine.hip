@@ -1105,6 +1105,15 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   }
 }
 
+// write-once output streams (`face`, thermometer planes): nontemporal 16-byte stores.  Measured on k_observe
+// at 524,288 tables (0.6-1.2 GB per call): 3.1 TB/s with plain stores, 5.3-5.7 TB/s with these.
+__device__ __forceinline__ void store_stream(float4* p, const float4 v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z);
+  __builtin_nontemporal_store(v.w, &p->w);
+}
+
 // ------------------------------------------------------------------------------------
 // k_slab: ONE lock-step iteration of a policy-driven loop in the slab layout (ddz_step_slab): apply the selections to
 // the lists the previous launch left in the slabs, then write the lists of the new states (game.py:95-106 +
@@ -1133,7 +1142,13 @@ struct SlabArgs {
   uint4* traj;          // [T][2] or null
   int64_t* wave_stats;
   int32_t* status;
+  // fused policy iteration (ddz_policy_step_slab): MODE = STEP_Q reads per-move values instead of selections
+  uint64_t thr;         // floor(epsilon * 2^32): explore <=> draw.x < thr (as k_select)
+  int32_t* choice_out;  // [T] the selected list indices, or null
+  float4* face;         // [T][P][15] `face` of the NEW states, or null
+  int face_variant;
 };
+constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
 
 // per-lane constants of the arithmetic follow list: lanes 0 pass | 1..15 group of rank lane-1 | 16..28 bomb | 29 rocket
 struct FastLanes {
@@ -1207,6 +1222,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   __shared__ uint64_t s_stage[WPB][STAGE_CAP];
   __shared__ uint16_t s_svl[WPB][STAGE_CAP];
   __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  __shared__ uint4 s_face[MODE == STEP_Q ? WPB : 1][12];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
@@ -1218,18 +1234,49 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   int cnt_l = 0;          // lane i: size of the current list of table t0 + i
   int32_t sel_l = -1;     // lane i: CHOICE index / IDS action id of table t0 + i
   uint4 pre_row = make_uint4(0, 0, 0, 0);  // CHOICE: lane i prefetches the selected row of table t0 + i ...
+  constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
   if (lane < ntab) {
     if (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) sel_l = ((const int32_t*)a.sel)[t0 + lane];
     cnt_l = a.counts[t0 + lane];
     if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
-    if (MODE == DDZ_STEP_CHOICE && sel_l >= 0 && sel_l < a.stride) pre_row = a.rows[(t0 + lane) * a.stride + sel_l];
   }
+  if (MODE == STEP_Q) {
+    // the (epsilon-)greedy arg-max of DQNFirst (dqn.py:50-71) over each table's list, as k_select: the 64 lanes read
+    // the table's values coalesced, a butterfly keeps (larger value, smaller index); lane i keeps table t0 + i's index
+    for (int i = 0; i < ntab; ++i) {
+      const int A = (int)rl((uint32_t)cnt_l, i);
+      const float* qrow = (const float*)a.sel + (t0 + i) * a.stride;
+      int best = 0x7FFFFFFF;
+      float bq = 0.f;
+      for (int j = lane; j < A; j += 64) {
+        const float v = qrow[j];
+        if (j == 0 || (v == v && (best == 0x7FFFFFFF || v > bq))) { bq = v; best = j; }
+      }
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const float oq = __shfl_xor(bq, dd);
+        const int ob = __shfl_xor(best, dd);
+        const bool have = best != 0x7FFFFFFF, ohave = ob != 0x7FFFFFFF;
+        if (ohave && (!have || (ob < best ? !(bq > oq) : (oq > bq)))) { bq = oq; best = ob; }
+      }
+      if (A <= 0) best = -1;
+      if (a.thr && A > 0) {
+        const uint4 meta = *(const uint4*)(a.state + (t0 + i) * STATE_ROW_BYTES + DDZ_F_META * 16);
+        const uint64_t g_ = a.gid_base + (uint64_t)(t0 + i);
+        const uint4 dr = philox4x32_10(make_uint4((uint32_t)g_, (uint32_t)(g_ >> 32), meta.z, (3u << 16) | (meta.y & 0xFFFF)), a.k0, a.k1);
+        if ((uint64_t)dr.x < a.thr) best = (int)__umulhi(dr.y, (uint32_t)A);
+      }
+      if (lane == i) sel_l = best;
+    }
+    if (a.choice_out && lane < ntab) a.choice_out[t0 + lane] = sel_l;
+  }
+  if (BYIDX && lane < ntab && sel_l >= 0 && sel_l < a.stride) pre_row = a.rows[(t0 + lane) * a.stride + sel_l];
   hot_fill<TB>(hot);
   __syncthreads();
   TACC(0);
   // ... and packs / classifies it (lane-parallel: the scalar unit is the bottleneck of this kernel)
   uint32_t pre_info = 0;  // category | value << 8 | len << 16 | number of cards << 24
-  if (MODE == DDZ_STEP_CHOICE) {
+  if (BYIDX) {
     if (sel_l < 0 || sel_l >= cnt_l) sel_l = -1;
     const uint64_t pn = pack_row(pre_row);
     pre_info = info_of_row(pn, (int)(pre_row.w >> 24)) | ((uint32_t)nib_sum(pn) << 24);
@@ -1267,9 +1314,9 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     int idx = -1;
     uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, the same value in every lane
     uint32_t cinfo = 0;                 // its category | value << 8 | len << 16 | number of cards << 24
-    const int32_t sel_i = (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) ? (int32_t)rl((uint32_t)sel_l, i) : 0;
+    const int32_t sel_i = (BYIDX || MODE == DDZ_STEP_IDS) ? (int32_t)rl((uint32_t)sel_l, i) : 0;
     if (!frozen) {
-      if (MODE == DDZ_STEP_CHOICE) {
+      if (BYIDX) {
         idx = sel_i;
         if (idx >= 0) {
           c = make_uint4(rl(pre_row.x, i), rl(pre_row.y, i), rl(pre_row.z, i), rl(pre_row.w, i));
@@ -1370,6 +1417,39 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     if (live) n = slab_list<IDS>(qhand, rfl(qinfo), t * a.stride, a.stride, a.rows, a.ids, stage, svl, sid, hot, lane, fl, a.status);
     if (lane == 0) a.counts[t] = n;
     s_rows += n;
+    if (MODE == STEP_Q && a.face) {
+      // `face` of the table as it now stands (k_observe's expression; envi.py:87-96,165-217): the wave's rows go through
+      // LDS so that lane e can read the byte of (plane, rank) = (e / 15, e % 15)
+      uint8_t* rb = (uint8_t*)s_face[wv];
+      if (lane < DDZ_NFIELDS) s_face[wv][lane] = R;
+      __builtin_amdgcn_wave_barrier();
+      const int v_ = a.face_variant;
+      const int P = v_ == 0 ? 4 : v_ == 1 ? 7 : v_ == 2 ? 9 : 6;
+      const uint64_t KINDS = v_ == 0 ? 0x8710ull : v_ == 1 ? 0x8743210ull : v_ == 2 ? 0x876543210ull : 0x876510ull;
+      int frole = rb[DDZ_F_META * 16];
+      if (frole > 2) frole = 0;
+      const int fm1 = frole == 0 ? 2 : frole - 1, fp1 = frole == 2 ? 0 : frole + 1;
+      const int n1 = rb[(DDZ_F_HAND0 + fp1) * 16 + 15], n2 = rb[(DDZ_F_HAND0 + fm1) * 16 + 15];
+      for (int e = lane; e < P * 15; e += 64) {
+        const int pl = e / 15, ri = e - pl * 15;
+        const int kind = (int)((KINDS >> (4 * pl)) & 15);
+        float4 v;
+        if (kind < 7) {
+          const int f = kind == 0 ? DDZ_F_HAND0 + frole : kind == 1 ? DDZ_F_TAKEN
+                      : kind == 2 ? DDZ_F_HIST0 + fm1 : kind == 3 ? DDZ_F_HIST0 + frole
+                      : kind == 4 ? DDZ_F_HIST0 + fp1 : kind == 5 ? DDZ_F_RECENT0 + fm1 : DDZ_F_RECENT0 + fp1;
+          const int c_ = rb[f * 16 + ri];
+          v = make_float4(c_ > 0 ? 1.f : 0.f, c_ > 1 ? 1.f : 0.f, c_ > 2 ? 1.f : 0.f, c_ > 3 ? 1.f : 0.f);
+        } else {
+          const int known = rb[(DDZ_F_HAND0 + frole) * 16 + ri] + rb[DDZ_F_TAKEN * 16 + ri], total = ri < 13 ? 4 : 1;
+          const float fr = n1 + n2 > 0 ? (float)(kind == 7 ? n1 : n2) / (float)(n1 + n2) : 0.f;
+          v = make_float4((0 >= known && 0 < total) ? fr : 0.f, (1 >= known && 1 < total) ? fr : 0.f,
+                          (2 >= known && 2 < total) ? fr : 0.f, (3 >= known && 3 < total) ? fr : 0.f);
+        }
+        store_stream(&a.face[t * (P * 15) + e], v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     TACC(4);
   }
 #ifdef DDZ_STAMP
@@ -1599,15 +1679,6 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_stats(Scratch sc, int64_t nslo
 // plane kinds: 0 hand 1 taken 2..4 history of (role-1, role, role+1) 5,6 recent handout of
 // (role-1, role-2) 7,8 prob planes (spec v1; native get_state_prob is absent).
 // variant 0: {0,1,7,8}  1: {0,1,2,3,4,7,8}  2: {0,..,8}  3: {0,1,5,6,7,8}   (envi.py:87-96,165-217)
-
-// write-once output streams (`face`, thermometer planes): nontemporal 16-byte stores.  Measured on k_observe
-// at 524,288 tables (0.6-1.2 GB per call): 3.1 TB/s with plain stores, 5.3-5.7 TB/s with these.
-__device__ __forceinline__ void store_stream(float4* p, const float4 v) {
-  __builtin_nontemporal_store(v.x, &p->x);
-  __builtin_nontemporal_store(v.y, &p->y);
-  __builtin_nontemporal_store(v.z, &p->z);
-  __builtin_nontemporal_store(v.w, &p->w);
-}
 
 // VARIANT is a template parameter: the divisions by P * 15 and by 15 are by constants (a 64-bit runtime
 // division per 16-byte store made the first version instruction-bound at half the HBM write rate) and the
@@ -2076,6 +2147,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.auto_reset = auto_reset ? 1 : 0; a.sel = sel; a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride;
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
+  a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)e->nblocks), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
@@ -2091,6 +2163,29 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   }
 #undef DDZ_LAUNCH_SLAB
   e->counts_valid = false;  // the state moved on without refreshing the CSR scan buffers
+  return check_launch();
+}
+
+int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* counts, int8_t* rows, int32_t* ids,
+                         int64_t stride, int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj,
+                         int32_t* choice, int face_variant, float* face, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(traj, 16) || !al(q, 4) || !al(choice, 4) || !al(face, 16)) return DDZ_EINVAL;
+  if (!q || !counts || !rows || stride < DDZ_SLAB_MIN_STRIDE || !(epsilon >= 0.0) || epsilon > 1.0) return DDZ_EINVAL;
+  if (face && ddz_face_planes(face_variant) < 0) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  SlabArgs a;
+  a.state = e->state; a.T = e->T; a.tpw = e->tpw;
+  a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
+  a.auto_reset = auto_reset ? 1 : 0; a.sel = q; a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride;
+  a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
+  a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
+  a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
+  const dim3 grid((unsigned)e->nblocks), block(TB);
+  if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
+  e->counts_valid = false;
   return check_launch();
 }
 

@@ -296,6 +296,35 @@ class BatchedEnv:
         self._legal_fresh, self._slab_fresh = False, True  # the buffers hold the lists of the new states
         return self.done, self.reward, self.illegal
 
+    def policy_step_slab(self, q, epsilon=0.0, face_variant=None, face_out=None, choice_out=None, auto_reset=True,
+                         traj=None):
+        """The environment side of one lock-step iteration of a value-based policy in ONE launch: (epsilon-)greedy
+        arg-max of q [T, stride] over each table's slab list (= select_slab), apply it (= step_slab), write the new
+        lists and, with face_variant, the `face` [T,P,15,4] of the new states (= observe).  Returns (done, r, illegal,
+        face | None); bit-identical to the three separate calls."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        if q.numel() != self.T * self.slab_stride:
+            raise ValueError("q must be [T, stride]")
+        face = None
+        if face_variant is not None:
+            P = FACE_PLANES[face_variant]
+            face = face_out if face_out is not None else torch.empty((self.T, P, 15, 4), dtype=torch.float32, device=self.device)
+            if face.dtype != torch.float32 or face.numel() != self.T * P * 60 or not face.is_contiguous():
+                raise ValueError(f"face_out must be a contiguous float32 [T,{P},15,4] tensor")
+        if traj is not None and (traj.dtype != torch.uint8 or traj.numel() != self.T * TRAJ_BYTES or not traj.is_contiguous()):
+            raise ValueError("traj must be a contiguous uint8 [T,32] tensor")
+        if choice_out is not None and (choice_out.dtype != torch.int32 or choice_out.numel() != self.T):
+            raise ValueError("choice_out must be int32 [T]")
+        check(self.lib.ddz_policy_step_slab(self._h, _p(q), float(epsilon), _p(self.counts), _p(self.rows), _p(self.ids),
+                                            self.slab_stride, int(bool(auto_reset)), _p(self.done), _p(self.reward),
+                                            _p(self.illegal), _p(traj), _p(choice_out),
+                                            int(face_variant) if face_variant is not None else 0, _p(face),
+                                            _stream(self.device)))
+        self._legal_fresh, self._slab_fresh = False, True
+        return self.done, self.reward, self.illegal, face
+
     def rollout_random(self, n_iters, traj=None):
         """n_iters lock-step iterations of {legal list, step_random(auto_reset)}
         (game.py:169-181 with envi.py:79-85), one kernel launch each.  The lists of the last

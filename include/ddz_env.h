@@ -133,6 +133,15 @@ int ddz_step_slab(ddz_env_t* env, int mode, const void* sel, int32_t* counts, in
                   int64_t stride, int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj,
                   void* stream);
 
+/* The environment side of one lock-step iteration of a value-based policy in ONE launch (game.py:95-104 with
+ * dqn.py:50-71): choose each table's move as the (epsilon-)greedy arg-max of q over its current slab list
+ * (= ddz_select_slab: q f32 [T][stride], first maximum, engine RNG domain 3), apply it (= ddz_step_slab CHOICE), write the
+ * lists of the new states and -- face != NULL -- their `face` tensors (= ddz_observe(face_variant): f32 [T][P][15][4]).
+ * choice (may be NULL) receives the selected list indices.  Bit-identical to the three separate calls.          */
+int ddz_policy_step_slab(ddz_env_t* env, const float* q, double epsilon, int32_t* counts, int8_t* rows, int32_t* ids,
+                         int64_t stride, int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj,
+                         int32_t* choice, int face_variant, float* face, void* stream);
+
 /* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
 int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
 

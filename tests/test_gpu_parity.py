@@ -427,6 +427,41 @@ def test_select_long_lists_ties_and_nans(pkg, oracle):
         env.reset(); ref.reset()                   # next episode: new 20-card leads
 
 
+@pytest.mark.parametrize("eps,variant,want_ids", [(0.0, 3, True), (0.3, 2, False), (0.0, 0, True), (1.0, 1, True)])
+def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids):
+    """ddz_policy_step_slab (select + step + new lists + face in ONE launch) == select_slab -> step_slab -> observe:
+    choices, done / r / illegal, trajectory records, states, lists and `face` bit-identical, every iteration."""
+    T = 3000
+    a = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
+    b = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
+    a.reset(); b.reset()
+    a.legal_slab(); b.legal_slab()
+    g = torch.Generator().manual_seed(9)
+    P = pkg.FACE_PLANES[variant]
+    for it in range(70):
+        q = torch.randint(-2, 3, (T, a.slab_stride), generator=g).float().to(_dev())   # ties on purpose
+        auto = it % 6 != 5
+        ta = torch.zeros((T, 32), dtype=torch.uint8, device=_dev())
+        tb = torch.zeros((T, 32), dtype=torch.uint8, device=_dev())
+        ca = torch.empty(T, dtype=torch.int32, device=_dev())
+        da, ra, ia, fa = a.policy_step_slab(q, eps, face_variant=variant, choice_out=ca, auto_reset=auto, traj=ta)
+        cb = b.select_slab(q, eps)
+        db, rb, ib = b.step_slab(cb, pkg.STEP_CHOICE, auto_reset=auto, traj=tb)
+        fb = b.observe(variant)
+        assert torch.equal(ca, cb) and torch.equal(da, db) and torch.equal(ra, rb) and torch.equal(ia, ib), it
+        assert torch.equal(ta, tb) and torch.equal(a.state, b.state) and torch.equal(a.counts, b.counts), it
+        assert fa.shape == (T, P, 15, 4) and torch.equal(fa.view(torch.int32), fb.view(torch.int32)), it
+        m = torch.arange(a.slab_stride, device=_dev())[None, :] < a.counts[:, None]
+        assert torch.equal(a.slab_rows()[m], b.slab_rows()[m])
+        if want_ids:
+            assert torch.equal(a.slab_ids()[m], b.slab_ids()[m])
+        if it % 12 == 11:
+            mk = a.field(10)[:, 1] != 0
+            a.reset(mask=mk); b.reset(mask=mk)
+            a.legal_slab(); b.legal_slab()
+    assert a.status() == 0 and a.stats() == b.stats()
+
+
 def test_step_onehot_matches_step_choice(pkg):
     """batched step_manual with [T,15,4] thermometer actions == stepping by list index"""
     T = 1024
@@ -878,7 +913,7 @@ def test_bench_contract():
     assert isinstance(j["config"]["csr_env_steps_per_s"], float) and j["config"]["csr_env_steps_per_s"] > 1e7
     assert r["issue"] is None or (r["issue"]["bound"] == "valu-issue" and 0 < r["issue"]["frac"] < 1)
     legs = j["configs"]
-    for k in ("tables_65536_random_rollout", "tables_65536_policy_loop_slab", "tables_65536_step_slab_only",
+    for k in ("tables_65536_random_rollout", "tables_65536_policy_loop_slab", "tables_65536_policy_loop_fused", "tables_65536_step_slab_only",
               "tables_65536_rule_opponent"):
         assert legs[k]["env_steps_per_s"] > 1e6, (k, legs)
     ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
