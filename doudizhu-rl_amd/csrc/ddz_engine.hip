@@ -1287,6 +1287,8 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   const FastLanes fl = fast_lanes(lane);
   int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
   int64_t s_rows = 0;
+  uint32_t out_l = 0;  // lane i: done | reward << 8 | illegal << 16 of table t0 + i; n_l: the size of its new list
+  int n_l = 0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
@@ -1404,18 +1406,14 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
         else qinfo = ((nz >> (DDZ_F_RECENT0 + rm1)) & 1u) ? rl(infoL, DDZ_F_RECENT0 + rm1) : mk_info(EMPTY, 0, 1);
       }
     }
-    if (lane == 0) {
-      if (a.done) a.done[t] = (uint8_t)o_done;
-      if (a.reward) a.reward[t] = (int8_t)o_reward;
-      if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
-    }
+    if (lane == i) out_l = (o_done & 0xFF) | ((o_reward & 0xFF) << 8) | ((o_illegal & 0xFF) << 16);
     if (a.traj && lane < 2) a.traj[2 * t + lane] = sel4(lane == 0, tr0, tr1);
     if (changed && lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
     TACC(3);
     // ---- the list of the (new) state, straight into the table's slab
     int n = 0;
     if (live) n = slab_list<IDS>(qhand, rfl(qinfo), t * a.stride, a.stride, a.rows, a.ids, stage, svl, sid, hot, lane, fl, a.status);
-    if (lane == 0) a.counts[t] = n;
+    if (lane == i) n_l = n;
     s_rows += n;
     if (MODE == STEP_Q && a.face) {
       // `face` of the table as it now stands (k_observe's expression; envi.py:87-96,165-217): the wave's rows go through
@@ -1458,6 +1456,12 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     for (int q = 0; q < 8; ++q) g_stamps[16 * t0 + q] = tacc[q];
   }
 #endif
+  if (lane < ntab) {  // the per-table outputs of the wave's tables: consecutive addresses, one store each
+    a.counts[t0 + lane] = n_l;
+    if (a.done) a.done[t0 + lane] = (uint8_t)out_l;
+    if (a.reward) a.reward[t0 + lane] = (int8_t)(out_l >> 8);
+    if (a.illegal) a.illegal[t0 + lane] = (uint8_t)(out_l >> 16);
+  }
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;

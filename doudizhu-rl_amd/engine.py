@@ -277,7 +277,8 @@ class BatchedEnv:
         if not self._slab_fresh:
             self.legal_slab()
         if mode in (STEP_CHOICE, STEP_IDS):
-            sel = sel.to(device=self.device, dtype=torch.int32).contiguous()
+            if sel.dtype != torch.int32 or sel.device != self.device or not sel.is_contiguous():  # (the host side of a
+                sel = sel.to(device=self.device, dtype=torch.int32).contiguous()                  # call costs ~10 us)
             if sel.numel() != self.T:
                 raise ValueError("choice / ids must have one entry per table")
         elif mode == STEP_ROWS:
