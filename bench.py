@@ -223,21 +223,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- headline: the K-iteration launch, repeated until >= 50 ms are timed (same repeat count on every rank)
+    # ---- headline: the K steps, repeated until >= 50 ms are timed (same repeat count on every rank).  The engine runs
+    # any number of lock-step iterations per launch; a launch carries at least 1000 of them (a multiple of K), so that a
+    # small --steps does not turn the figure into a launch-latency measurement (a launch costs ~25 us of ramp-up)
+    KL = K if K >= 1000 else K * math.ceil(1000 / K)   # iterations per launch
     env.rollout_random(W)
     barrier()
     t0 = time.perf_counter()
-    env.rollout_random(K)
+    env.rollout_random(KL)
     torch.cuda.synchronize(dev)
     est = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(est, op=dist.ReduceOp.MIN)
-    R = int(min(1 << 16, max(1, math.ceil(MIN_TIMED_S / max(float(est.item()), 1e-6)))))
+    RL = int(min(1 << 16, max(1, math.ceil(MIN_TIMED_S / max(float(est.item()), 1e-6)))))   # launches timed
+    R = RL * (KL // K)                                                                      # repeats of the K steps
     s0 = env.stats()  # cumulative counters so far (sync)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(R):
-        env.rollout_random(K)
+    for _ in range(RL):
+        env.rollout_random(KL)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -289,7 +293,7 @@ def main():
                 # digest of every gathered record in (iteration, global table) order: the rehearsal test recomputes it
                 # from a single-process rollout of the union of the shards
                 digest = int((x * 31 + (x >> 13) + torch.arange(x.numel(), device=dev) * x).sum().item())
-            exchange = {"steps": KX, "iterations_before": W + K * (R + 1), "env_steps_per_s_with_gather": total_tables * KX / dtx,
+            exchange = {"steps": KX, "iterations_before": W + KL * (RL + 1), "env_steps_per_s_with_gather": total_tables * KX / dtx,
                         "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_PACKED_BYTES, "seconds": dtx, "digest": digest,
                         "note": "trajectory records (32 B per ply per table) written, packed to 8 B and gathered to rank 0, pipelined "
                                 "in two half-batches; measured after the headline region"}
@@ -304,7 +308,7 @@ def main():
     sa = env.stats()
     ms_total, n_launch = 0.0, 0
     while ms_total < MIN_TIMED_S * 1e3 and n_launch < (1 << 16):
-        ms_total += env.rollout_random_timed(K)
+        ms_total += env.rollout_random_timed(KL)
         n_launch += 1
     sb = env.stats()
     steps_timed = sb["plies"] - sa["plies"]
@@ -338,7 +342,8 @@ def main():
             "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / (K * R) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "timed_steps": K * R, "repeats_of_the_steps_launch": R, "timed_seconds": dt,
+            "timed_steps": K * R, "repeats_of_the_steps_launch": R, "iterations_per_launch": KL, "launches_timed": RL,
+            "timed_seconds": dt,
             "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list only (no NN), "
                                    f"auto-reset; BASELINE.json {'configs[1]' if world == 1 else 'configs[4] (65,536 tables per GPU)'}",
                        "tables_per_gpu": T, "total_tables": total_tables,
@@ -349,7 +354,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
                          "launch_us": dur_launch * 1e6, "launches_timed": n_launch, "env_steps_per_launch": steps_per_launch,
-                         "us_per_iteration": dur_launch * 1e6 / K,
+                         "us_per_iteration": dur_launch * 1e6 / KL, "iterations_per_launch": KL,
                          "algorithmic_bytes_per_env_step": b_step,
                          "algorithmic_bytes_per_launch": b_launch,
                          "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / launch time: a store rate into the write-back "

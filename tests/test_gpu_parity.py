@@ -905,10 +905,11 @@ def test_bench_contract():
     assert j["value"] > 1e8 and abs(j["ms_per_step"] * 1e-3 * j["value"] - 4096) < 1
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
-    assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 4096 * 300
+    assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 4096 * j["iterations_per_launch"]
     assert "workload" in j["config"] and "model" not in j["config"]
     # self-sufficient timing: the 300-iteration launch is repeated until >= 50 ms are timed
     assert j["timed_steps"] == 300 * j["repeats_of_the_steps_launch"] and j["timed_seconds"] >= 0.045
+    assert j["iterations_per_launch"] == 1200   # four times the 300 steps: a launch carries >= 1000 iterations
     assert r["launches_timed"] >= 2 and r["launch_us"] * r["launches_timed"] >= 45e3
     assert isinstance(j["config"]["csr_env_steps_per_s"], float) and j["config"]["csr_env_steps_per_s"] > 1e7
     assert r["issue"] is None or (r["issue"]["bound"] == "valu-issue" and 0 < r["issue"]["frac"] < 1)
