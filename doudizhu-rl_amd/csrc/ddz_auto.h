@@ -169,6 +169,10 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
         active = false;
       }
     }
+    if (active && nib_sum(hand) > 20) {  // no player ever holds more than 20 cards: the search is sized for that
+      if (lane == 0 && a.status) atomicOr(a.status, 4);
+      active = false;
+    }
     if (!active || hand == 0) {
       if (lane == 0) {
         a.ids[t] = -1;
