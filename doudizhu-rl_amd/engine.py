@@ -72,6 +72,8 @@ class BatchedEnv:
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self._stats = torch.zeros(8, dtype=torch.int64, device=d)
         self._legal_fresh = self._slab_fresh = False
+        # raw pointers of the persistent buffers, converted once (the host side of a call is ~10 us of ctypes work)
+        self._pp = {k: _p(getattr(self, k)) for k in ("counts", "rows", "ids", "done", "reward", "illegal", "offsets")}
         h = C.c_void_p()
         check(self.lib.ddz_create(C.byref(h), self.T, self.seed, self.table_id_base, d.index,
                                   _p(self.state), self.state.numel(), _p(self.scratch),
@@ -211,12 +213,13 @@ class BatchedEnv:
         int32[T] indices for step_slab(STEP_CHOICE).  Same greedy / epsilon-greedy rule and RNG as select()."""
         if not self._slab_fresh:
             self.legal_slab()
-        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        if q.dtype != torch.float32 or q.device != self.device or not q.is_contiguous():
+            q = q.to(device=self.device, dtype=torch.float32).contiguous()
         if q.numel() != self.T * self.slab_stride:
             raise ValueError("q must be [T, stride]")
         if out is None:
             out = torch.empty(self.T, dtype=torch.int32, device=self.device)
-        check(self.lib.ddz_select_slab(self._h, _p(q), _p(self.counts), self.slab_stride, float(epsilon), _p(out),
+        check(self.lib.ddz_select_slab(self._h, _p(q), self._pp["counts"], self.slab_stride, float(epsilon), _p(out),
                                        _stream(self.device)))
         return out
 
@@ -290,9 +293,10 @@ class BatchedEnv:
         if traj is not None and (traj.dtype != torch.uint8 or traj.numel() != self.T * TRAJ_BYTES
                                  or not traj.is_contiguous()):
             raise ValueError("traj must be a contiguous uint8 [T,32] tensor")
-        check(self.lib.ddz_step_slab(self._h, mode, _p(sel) if mode != STEP_RANDOM else None, _p(self.counts),
-                                     _p(self.rows), _p(self.ids), self.slab_stride, int(bool(auto_reset)),
-                                     _p(self.done), _p(self.reward), _p(self.illegal), _p(traj),
+        pp = self._pp
+        check(self.lib.ddz_step_slab(self._h, mode, _p(sel) if mode != STEP_RANDOM else None, pp["counts"],
+                                     pp["rows"], pp["ids"], self.slab_stride, 1 if auto_reset else 0,
+                                     pp["done"], pp["reward"], pp["illegal"], _p(traj),
                                      _stream(self.device)))
         self._legal_fresh, self._slab_fresh = False, True  # the buffers hold the lists of the new states
         return self.done, self.reward, self.illegal
@@ -305,7 +309,8 @@ class BatchedEnv:
         face | None); bit-identical to the three separate calls."""
         if not self._slab_fresh:
             self.legal_slab()
-        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        if q.dtype != torch.float32 or q.device != self.device or not q.is_contiguous():
+            q = q.to(device=self.device, dtype=torch.float32).contiguous()
         if q.numel() != self.T * self.slab_stride:
             raise ValueError("q must be [T, stride]")
         face = None
@@ -318,9 +323,10 @@ class BatchedEnv:
             raise ValueError("traj must be a contiguous uint8 [T,32] tensor")
         if choice_out is not None and (choice_out.dtype != torch.int32 or choice_out.numel() != self.T):
             raise ValueError("choice_out must be int32 [T]")
-        check(self.lib.ddz_policy_step_slab(self._h, _p(q), float(epsilon), _p(self.counts), _p(self.rows), _p(self.ids),
-                                            self.slab_stride, int(bool(auto_reset)), _p(self.done), _p(self.reward),
-                                            _p(self.illegal), _p(traj), _p(choice_out),
+        pp = self._pp
+        check(self.lib.ddz_policy_step_slab(self._h, _p(q), float(epsilon), pp["counts"], pp["rows"], pp["ids"],
+                                            self.slab_stride, 1 if auto_reset else 0, pp["done"], pp["reward"],
+                                            pp["illegal"], _p(traj), _p(choice_out),
                                             int(face_variant) if face_variant is not None else 0, _p(face),
                                             _stream(self.device)))
         self._legal_fresh, self._slab_fresh = False, True

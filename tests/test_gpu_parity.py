@@ -323,9 +323,10 @@ def test_full_deck_hand_lists_every_action(pkg):
     assert torch.equal(ids.cpu(), torch.arange(1, NA, dtype=torch.int32))
 
 
-@pytest.mark.parametrize("T", [4096, 65536])
+@pytest.mark.parametrize("T", [4096, 65536, 524288])
 def test_full_size_properties(pkg, T):
-    """BASELINE sizes: size-independent invariants after a seeded random-policy rollout."""
+    """BASELINE sizes (524,288 = all tables of configs[4] on one GPU): size-independent invariants after a seeded
+    random-policy rollout."""
     iters = 150
     env = pkg.BatchedEnv(T, seed=77)
     env.reset()
