@@ -29,6 +29,7 @@
  */
 #include "ddz_oracle.h"
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -82,7 +83,10 @@ static double eval_row(int id) {
   return val - 7;                                         /* :50-51 four-with-two */
 }
 
-static void auto_init(void) {
+static pthread_once_t a_once = PTHREAD_ONCE_INIT;
+static void auto_init_once(void);
+static void auto_init(void) { pthread_once(&a_once, auto_init_once); } /* the tests call the oracle from thread pools */
+static void auto_init_once(void) {
   if (a_ready) return;
   ddzo_init();
   if (ddzo_num_actions() == NAB) {

@@ -92,6 +92,7 @@ def lib():
         L.ddzo_auto_choose.restype = C.c_int
         L.ddzo_env_auto_choose.argtypes = [p, C.c_int64, C.c_int, p, p]
         L.ddzo_init()
+        L.ddzo_cards_value_x2(_ptr(np.zeros(NUM_ACTIONS, np.int16)))  # builds the rule agent's tables now, on this thread
         _libs[_jk] = L
     return _libs[_jk]
 
