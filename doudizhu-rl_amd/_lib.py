@@ -40,6 +40,8 @@ SYMBOLS = {
     "ddz_rows_to_onehot": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_get_moves": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddz_get_moves_slab": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_rollout_random": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_rollout_random_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

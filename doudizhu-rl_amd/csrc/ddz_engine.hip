@@ -1200,7 +1200,7 @@ __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t b
     n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
     __builtin_amdgcn_wave_barrier();
     if (n > STAGE_CAP || n > stride) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
-      if (lane == 0) atomicOr(status, 2);
+      if (lane == 0 && status) atomicOr(status, 2);
       n = 0;
     }
     for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
@@ -1466,6 +1466,44 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
   }
+}
+
+// stateless r.get_moves(hand15, last15) in the slab layout: query i owns rows[i * stride ...], ONE launch, no size pass
+// and no scan over the queries (k_moves needs both for its packed CSR output); the list code is k_slab's.
+template <bool IDS>
+__global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ hands, const uint4* __restrict__ lasts,
+                                                      int64_t n, int tpw, int32_t* __restrict__ counts,
+                                                      uint4* __restrict__ rows, int32_t* __restrict__ ids, int64_t stride,
+                                                      int32_t* __restrict__ status) {
+  __shared__ HotTabT<false> hot;
+  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
+  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
+  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
+  const int ntab = t0 < n ? (int)(n - t0 < tpw ? n - t0 : tpw) : 0;
+  uint4 hr = make_uint4(0, 0, 0, 0), lr = hr;  // lane i: the rows of query t0 + i
+  if (lane < ntab) { hr = hands[t0 + lane]; lr = lasts[t0 + lane]; }
+  hot_fill<TB>(hot);
+  __syncthreads();
+  // pack / classify lane-parallel, then one readlane per value and query
+  const uint64_t hn = pack_row(hr);
+  uint32_t li = classify(pack_row(lr));
+  if (li == INFO_INVALID || ge_mask(hn, 5) || (hn >> 60)) li = QF_BADLAST | QF_FROZEN;
+  const FastLanes fl = fast_lanes(lane);
+  int n_l = 0;
+  bool bad = false;
+  for (int i = 0; i < ntab; ++i) {
+    const uint64_t hand = rl64(hn, i);
+    const uint32_t info = rl(li, i);
+    bad = bad || (info & QF_BADLAST);
+    const int m = slab_list<IDS>(hand, info, (t0 + i) * stride, stride, rows, ids, s_stage[wv], s_svl[wv], s_sid[IDS ? wv : 0],
+                                 hot, lane, fl, status);
+    if (lane == i) n_l = m;
+  }
+  if (lane < ntab) counts[t0 + lane] = n_l;
+  if (bad && lane == 0 && status) atomicOr(status, 4);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2261,6 +2299,28 @@ int ddz_get_moves(int device, const int8_t* hands, const int8_t* lasts, int64_t 
   int rc = ensure_table(device);
   if (rc) return rc;
   return launch_moves(bind(scratch, l), hands, lasts, n, offsets, rows, ids, cap, (hipStream_t)stream);
+}
+
+int ddz_get_moves_slab(int device, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* counts, int8_t* rows,
+                       int32_t* ids, int64_t stride, int32_t* status, void* stream) {
+  if (!al(hands, 16) || !al(lasts, 16) || !al(rows, 16) || !al(counts, 4) || !al(ids, 4) || !al(status, 4)) return DDZ_EINVAL;
+  if (n <= 0 || !hands || !lasts || !counts || !rows || stride < DDZ_SLAB_MIN_STRIDE) return DDZ_EINVAL;
+  if (n > ((int64_t)1 << 30) || n * stride > 0x7FFFFFFFll * 16) return DDZ_ECAP;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  int64_t v = (n + 4095) / 4096;
+  const int tpw = (int)(v < 1 ? 1 : v > 32 ? 32 : v);
+  const int64_t per_block = (int64_t)WPB * tpw;
+  const dim3 grid((unsigned)((n + per_block - 1) / per_block)), block(TB);
+  if (ids)
+    hipLaunchKernelGGL((k_moves_slab<true>), grid, block, 0, (hipStream_t)stream, (const uint4*)hands, (const uint4*)lasts, n,
+                       tpw, counts, (uint4*)rows, ids, stride, status);
+  else
+    hipLaunchKernelGGL((k_moves_slab<false>), grid, block, 0, (hipStream_t)stream, (const uint4*)hands, (const uint4*)lasts, n,
+                       tpw, counts, (uint4*)rows, ids, stride, status);
+  return check_launch();
 }
 
 int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {

@@ -522,3 +522,34 @@ def cards_value(device="cuda:0"):
     out = torch.empty(NUM_ACTIONS, dtype=torch.int8, device=dev)
     check(L.ddz_debug_cards_value(dev.index, _p(out), _stream(dev)))
     return out.to(torch.float64) / 2.0
+
+
+def get_moves_slab(hands, lasts, want_ids=True, native_joker_kickers=False, out=None):
+    """Batched r.get_moves(hand15, last15) in the slab layout, ONE launch and no host sync: returns (counts int32 [n],
+    rows int8 [n, 512, 16], ids int32 [n, 512] | None, status int32 [1]); query i's moves are rows[i, :counts[i]] in
+    ascending canonical id (pass first when following); status bit 2 = some `last` was no combo (its list is empty).
+    `out` = a previous result to write into (no allocation)."""
+    L = _lib.lib(jk=native_joker_kickers)
+    dev = _require_gpu(hands.device)
+
+    def pad(x):
+        x = x.to(device=dev, dtype=torch.int8)
+        if x.shape[1] == 15:
+            x = torch.nn.functional.pad(x, (0, 1))
+        return x.contiguous()
+
+    hands, lasts = pad(hands), pad(lasts)
+    n = hands.shape[0]
+    if lasts.shape[0] != n:
+        raise ValueError("hands and lasts must have the same length")
+    if out is None:
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        rows = torch.empty((n, MAX_LEGAL_PER_TABLE, ROW), dtype=torch.int8, device=dev)
+        ids = torch.empty((n, MAX_LEGAL_PER_TABLE), dtype=torch.int32, device=dev) if want_ids else None
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+        counts, rows, ids, status = out
+        status.zero_()
+    check(L.ddz_get_moves_slab(dev.index, _p(hands), _p(lasts), n, _p(counts), _p(rows), _p(ids), MAX_LEGAL_PER_TABLE,
+                               _p(status), _stream(dev)))
+    return counts, rows, ids, status

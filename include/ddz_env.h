@@ -163,6 +163,14 @@ int ddz_get_moves(int device_id, const int8_t* hands, const int8_t* lasts, int64
                   int32_t* offsets, int8_t* rows, int32_t* ids, int64_t row_capacity,
                   void* scratch, int64_t scratch_bytes, void* stream);
 
+/* ddz_get_moves in the slab layout (as ddz_legal_slab): query i owns rows[i * stride ... i * stride + counts[i]),
+ * ascending canonical id, pass first when following; stride >= DDZ_SLAB_MIN_STRIDE.  ONE launch, no scratch, no size
+ * pass: the low-latency form for a serving path (server/core.py:56-67 valid_actions).  status (device int32, may be
+ * NULL) gets bit 2 when a `last` is no combo of the action space (that query's list is empty) and bit 1 when a list
+ * does not fit (a hand of more than 20 cards can have more than 512 moves: use ddz_get_moves for those).            */
+int ddz_get_moves_slab(int device_id, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* counts, int8_t* rows,
+                       int32_t* ids, int64_t stride, int32_t* status, void* stream);
+
 /* The lock-step loop of Game.play under a random policy (game.py:169-181 with
  * envi.py:79-85): n_iters iterations of {legal list, step_random(auto_reset)} in ONE kernel
  * launch.  The lists are written in the SLAB layout: table t owns

@@ -463,6 +463,32 @@ def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids):
     assert a.status() == 0 and a.stats() == b.stats()
 
 
+def test_get_moves_slab_golden_and_csr(pkg, golden):
+    """ddz_get_moves_slab (one launch, slab layout) == the reference's legal sets (G3, G6) == ddz_get_moves (CSR);
+    a `last` that is no combo and a hand whose list does not fit are reported, not written."""
+    for name in ("legal_cases.npz", "legal_sweep.npz"):
+        g = golden(name)
+        table = golden("action_table.npz")["rows"]
+        hands = g["hands"].astype(np.int8)
+        lasts = table[g["last_ids"]].astype(np.int8)
+        small = hands.sum(1) <= 20
+        h, l = torch.from_numpy(hands[small]).to(_dev()), torch.from_numpy(lasts[small]).to(_dev())
+        counts, rows, ids, status = pkg.get_moves_slab(h, l)
+        off, crow, cid = pkg.get_moves(h, l)
+        c = counts.cpu().numpy().astype(np.int64)
+        assert int(status.item()) == 0
+        assert np.array_equal(np.concatenate([[0], np.cumsum(c)]), off.cpu().numpy())
+        take = (torch.arange(rows.shape[1], device=_dev())[None, :] < counts[:, None])
+        assert torch.equal(ids[take], cid) and torch.equal(rows[take], crow)
+        goff = g["offsets"].astype(np.int64)
+        want = np.concatenate([g["ids"][goff[k]:goff[k + 1]] for k in np.flatnonzero(small)]).astype(np.int32)
+        assert np.array_equal(ids[take].cpu().numpy(), want)
+    bad_last = torch.zeros((3, 15), dtype=torch.int8); bad_last[1, 0] = 1; bad_last[1, 2] = 1     # "3 5": no combo
+    hand = torch.zeros((3, 15), dtype=torch.int8); hand[:, :13] = 1; hand[2, :13] = 4; hand[2, 13:] = 1  # query 2: the full deck
+    counts, rows, ids, status = pkg.get_moves_slab(hand.to(_dev()), bad_last.to(_dev()))
+    assert counts.tolist()[1] == 0 and counts.tolist()[2] == 0 and counts.tolist()[0] > 13 and int(status.item()) == 6
+
+
 def test_step_onehot_matches_step_choice(pkg):
     """batched step_manual with [T,15,4] thermometer actions == stepping by list index"""
     T = 1024

@@ -26,3 +26,14 @@ for n in (4096, 65536, 524288):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"n={n:7d}: {dt * 1e6:9.1f} us per call  {n / dt / 1e6:8.1f} M queries/s  {int(off[-1]) / n:.2f} moves per query", flush=True)
+
+    out = pkg.get_moves_slab(h, l, want_ids=False)
+    for _ in range(2):
+        pkg.get_moves_slab(h, l, want_ids=False, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pkg.get_moves_slab(h, l, want_ids=False, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"n={n:7d}: {dt * 1e6:9.1f} us per call  {n / dt / 1e6:8.1f} M queries/s  (slab layout, one launch, no host sync)", flush=True)
