@@ -1506,6 +1506,79 @@ __global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ 
   if (bad && lane == 0 && status) atomicOr(status, 4);
 }
 
+// slab -> CSR: the fixed-stride lists packed into offsets[n+1] / rows[sum A] / ids[sum A] (what a ragged NN forward
+// consumes) -- the "prefix-sum compaction of the variable-length legal-action list" as its own cheap pass, so that the
+// stepping kernels never wait on a scan over all tables.  Two launches: sizes -> block scans, then offsets + row copy.
+constexpr int CSR_BT = 256;  // tables per block
+__global__ __launch_bounds__(CSR_BT) void k_csr_scan(const int32_t* __restrict__ counts, int64_t n, int64_t stride,
+                                                     int32_t* __restrict__ local_off, int32_t* __restrict__ blk_tot) {
+  __shared__ int sh[CSR_BT / 64];
+  const int64_t t = (int64_t)blockIdx.x * CSR_BT + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int c = t < n ? counts[t] : 0;
+  if (c < 0 || c > stride) c = 0;
+  const int incl = wave_incl_scan(c, lane);
+  if (lane == 63) sh[wv] = incl;
+  __syncthreads();
+  int wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < CSR_BT / 64; ++w) {
+    if (w < wv) wbase += sh[w];
+    tot += sh[w];
+  }
+  if (t < n) local_off[t] = wbase + incl - c;
+  if (threadIdx.x == 0) blk_tot[blockIdx.x] = tot;
+}
+
+template <bool IDS>
+__global__ __launch_bounds__(CSR_BT) void k_csr_copy(const int32_t* __restrict__ counts, const uint4* __restrict__ rows,
+                                                     const int32_t* __restrict__ ids, int64_t n, int64_t stride,
+                                                     const int32_t* __restrict__ local_off, const int32_t* __restrict__ blk_tot,
+                                                     int32_t* __restrict__ offsets, uint4* __restrict__ rows_out,
+                                                     int32_t* __restrict__ ids_out, int64_t cap, int32_t* __restrict__ status) {
+  __shared__ long long sh[CSR_BT / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  long long part = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += CSR_BT) part += blk_tot[j];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) sh[wv] = part;
+  __syncthreads();
+  long long base = 0;
+#pragma unroll
+  for (int w = 0; w < CSR_BT / 64; ++w) base += sh[w];
+  const int64_t t = (int64_t)blockIdx.x * CSR_BT + threadIdx.x;
+  int c = t < n ? counts[t] : 0;
+  if (c < 0 || c > stride) c = 0;
+  const long long off = base + (t < n ? local_off[t] : 0);
+  if (t < n) offsets[t] = (int32_t)off;
+  if (t == n - 1) {
+    offsets[n] = (int32_t)(off + c);
+    if (off + c > cap && status) atomicOr(status, 2);
+  }
+  // every wave copies the lists of its 64 tables flat: output row r of the wave belongs to the last table whose
+  // exclusive offset is <= r (binary search over 64 LDS words), so the loads of one trip are independent
+  __shared__ int s_excl[CSR_BT / 64][64];
+  const long long woff = (long long)rl64((uint64_t)off, 0);
+  const int64_t t0 = (int64_t)blockIdx.x * CSR_BT + wv * 64;
+  const int nv = n - t0 >= 64 ? 64 : (n > t0 ? (int)(n - t0) : 0);  // tables of this wave that exist
+  const int excl = lane < nv ? (int)(off - woff) : 0x7FFFFFFF;
+  s_excl[wv][lane] = excl;
+  const int W = nv ? (int)rl((uint32_t)(excl + c), nv - 1) : 0;
+  __builtin_amdgcn_wave_barrier();
+  for (int r = lane; r < W; r += 64) {
+    int i = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+      if (s_excl[wv][i + d] <= r) i += d;
+    const int j = r - s_excl[wv][i];
+    if (woff + r < cap) {
+      rows_out[woff + r] = rows[(t0 + i) * stride + j];
+      if (IDS) ids_out[woff + r] = ids[(t0 + i) * stride + j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // k_mask: the legal moves of every table as a dense 0/1 mask over the action space -- the form the reference's
 // rules produce (get_mask, rule_based/utils/utils.py:45-63; mask[0] = pass) and what a policy head with one logit
@@ -2320,6 +2393,29 @@ int ddz_get_moves_slab(int device, const int8_t* hands, const int8_t* lasts, int
   else
     hipLaunchKernelGGL((k_moves_slab<false>), grid, block, 0, (hipStream_t)stream, (const uint4*)hands, (const uint4*)lasts, n,
                        tpw, counts, (uint4*)rows, ids, stride, status);
+  return check_launch();
+}
+
+int ddz_slab_to_csr(ddz_env_t* e, const int32_t* counts, const int8_t* rows, const int32_t* ids, int64_t stride,
+                    int32_t* offsets, int8_t* rows_out, int32_t* ids_out, int64_t row_capacity, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(rows_out, 16) || !al(counts, 4) || !al(ids, 4) || !al(ids_out, 4) || !al(offsets, 4)) return DDZ_EINVAL;
+  if (!counts || !rows || !offsets || !rows_out || stride < 1 || row_capacity < 0 || (ids_out && !ids)) return DDZ_EINVAL;
+  if (row_capacity > 0x7FFFFFFF) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = (e->T + CSR_BT - 1) / CSR_BT;  // <= lay.nblk = ceil(T / 4)
+  e->counts_valid = false;                             // the scan buffers of the CSR path are reused here
+  hipLaunchKernelGGL(k_csr_scan, dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, e->T, stride, e->sc.local_off[0], e->sc.blk_tot[0]);
+  int rc = check_launch();
+  if (rc) return rc;
+  if (ids_out)
+    hipLaunchKernelGGL((k_csr_copy<true>), dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, (const uint4*)rows, ids, e->T, stride,
+                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status);
+  else
+    hipLaunchKernelGGL((k_csr_copy<false>), dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, (const uint4*)rows, ids, e->T, stride,
+                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status);
   return check_launch();
 }
 

@@ -332,6 +332,22 @@ class BatchedEnv:
         self._legal_fresh, self._slab_fresh = False, True
         return self.done, self.reward, self.illegal, face
 
+    def slab_to_csr(self, rows_per_table=64):
+        """The slab lists as CSR (offsets int32[T+1], rows int8[cap,16], ids int32[cap] | None) -- the layout legal()
+        returns and a ragged NN forward consumes -- by two small launches; list indices are the same in both layouts, so
+        select(q_csr) feeds step_slab(CHOICE).  cap = T * rows_per_table rows (mean list: 5.6 rows under a random
+        policy; the first lead of a game: ~73): a fuller list raises status bit 1 and is truncated."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        cap = self.T * int(rows_per_table)
+        if getattr(self, "_csr_cap", 0) != cap:
+            self.csr_rows = torch.empty((cap, ROW), dtype=torch.int8, device=self.device)
+            self.csr_ids = torch.empty(cap, dtype=torch.int32, device=self.device) if self.ids is not None else None
+            self._csr_cap = cap
+        check(self.lib.ddz_slab_to_csr(self._h, self._pp["counts"], self._pp["rows"], self._pp["ids"], self.slab_stride,
+                                       self._pp["offsets"], _p(self.csr_rows), _p(self.csr_ids), cap, _stream(self.device)))
+        return self.offsets, self.csr_rows, self.csr_ids
+
     def rollout_random(self, n_iters, traj=None):
         """n_iters lock-step iterations of {legal list, step_random(auto_reset)}
         (game.py:169-181 with envi.py:79-85), one kernel launch each.  The lists of the last

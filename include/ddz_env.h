@@ -142,6 +142,15 @@ int ddz_policy_step_slab(ddz_env_t* env, const float* q, double epsilon, int32_t
                          int64_t stride, int auto_reset, uint8_t* done, int8_t* reward, uint8_t* illegal, uint8_t* traj,
                          int32_t* choice, int face_variant, float* face, void* stream);
 
+/* Slab lists -> CSR (what ddz_legal writes, what a ragged NN forward over all legal moves consumes): offsets
+ * int32[T+1], rows_out int8[row_capacity][16], ids_out int32[row_capacity] (NULL: no ids).  The prefix-sum compaction of
+ * the variable-length lists as its own cheap pass (two small launches), so that ddz_step_slab / ddz_rollout_random
+ * never wait on a scan over all tables: legal lists in CSR order cost ddz_step_slab + this instead of ddz_legal +
+ * ddz_step.  A list index is the same in both layouts (ddz_select's choice feeds ddz_step_slab CHOICE).  Rows beyond
+ * row_capacity are dropped and status bit 1 is raised.                                                             */
+int ddz_slab_to_csr(ddz_env_t* env, const int32_t* counts, const int8_t* rows, const int32_t* ids, int64_t stride,
+                    int32_t* offsets, int8_t* rows_out, int32_t* ids_out, int64_t row_capacity, void* stream);
+
 /* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
 int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
 

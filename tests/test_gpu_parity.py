@@ -988,3 +988,31 @@ def test_bench_two_ranks_rehearsal_gathers_the_union(pkg):
     x = torch.cat([pkg.pack_trajectory(ta), pkg.pack_trajectory(tb)]).contiguous().view(torch.int64).view(-1)
     digest = int((x * 31 + (x >> 13) + torch.arange(x.numel(), device=_dev()) * x).sum().item())
     assert digest == ex["digest"]
+
+
+def test_slab_to_csr_equals_legal(pkg):
+    """ddz_slab_to_csr: the slab lists packed to CSR are byte-identical to ddz_legal's offsets / rows / ids on the same
+    states (ragged sizes, mid-game and fresh deals, a table count that is not a multiple of the block), a choice index
+    means the same move in both layouts, and an undersized buffer raises status bit 1 without writing past it."""
+    import torch
+    for T in (1, 257, 5000):
+        env = pkg.BatchedEnv(T, seed=31 + T, device=torch.device("cuda:0"))
+        env.reset()
+        env.rollout_random(7)
+        for rpt in (512,):
+            env.legal_slab()
+            off, rows, ids = env.slab_to_csr(rows_per_table=rpt)
+            off, tot = off.clone(), int(off[-1].item())
+            rows, ids = rows[:tot].clone(), ids[:tot].clone()
+            off2, rows2, ids2 = env.legal()
+            assert torch.equal(off, off2) and int(off2[-1].item()) == tot
+            assert torch.equal(rows, rows2[:tot]) and torch.equal(ids, ids2[:tot])
+        assert env.status() == 0
+    env = pkg.BatchedEnv(300, seed=5, device=torch.device("cuda:0"))
+    env.reset()
+    env.legal_slab()
+    total = int(env.counts.sum().item())
+    off, rows, ids = env.slab_to_csr(rows_per_table=8)          # a fresh lead has ~73 legal moves: 2400 rows do not fit
+    assert int(off[-1].item()) == total > 2400 and env.status() & 2
+    off2, rows2, ids2 = env.legal()
+    assert torch.equal(rows[:2400], rows2[:2400]) and torch.equal(ids[:2400], ids2[:2400])
