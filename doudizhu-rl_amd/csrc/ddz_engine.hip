@@ -1213,256 +1213,346 @@ __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t b
   return n;
 }
 
+// `face` of the tables of a chunk from their rows in LDS: element e = (table, plane, rank), one 16-byte store each,
+// consecutive elements -> consecutive addresses.  side[i] = row index per plane kind (bytes 0..6) | the two fractions.
+template <int P, uint64_t KINDS>
+__device__ __forceinline__ void face_chunk(const uint4* srow, const uint4* side, int ntab, float4* out, int lane) {
+  const uint8_t* rb = (const uint8_t*)srow;
+  const int ne = ntab * (P * 15);
+  for (int e = lane; e < ne; e += 64) {
+    const int i = e / (P * 15), r = e - i * (P * 15), pl = r / 15, ri = r - pl * 15;
+    const int kind = (int)((KINDS >> (4 * pl)) & 15);
+    const uint4 sd = side[i];
+    const uint8_t* tb = rb + i * STATE_ROW_BYTES;
+    const uint64_t rowsel = (uint64_t)sd.x | ((uint64_t)sd.y << 32);
+    const int f = (int)((rowsel >> (8 * (kind < 7 ? kind : 0))) & 0xFF);  // the prob planes read the actor's hand
+    const int c_ = tb[f * 16 + ri];
+    float4 v;
+    if (kind < 7) {
+      v = make_float4(c_ > 0 ? 1.f : 0.f, c_ > 1 ? 1.f : 0.f, c_ > 2 ? 1.f : 0.f, c_ > 3 ? 1.f : 0.f);
+    } else {
+      const int known = c_ + tb[DDZ_F_TAKEN * 16 + ri], total = ri < 13 ? 4 : 1;
+      const float fr = __uint_as_float(kind == 7 ? sd.z : sd.w);
+      v = make_float4((0 >= known && 0 < total) ? fr : 0.f, (1 >= known && 1 < total) ? fr : 0.f,
+                      (2 >= known && 2 < total) ? fr : 0.f, (3 >= known && 3 < total) ? fr : 0.f);
+    }
+    store_stream(&out[e], v);
+  }
+}
+
+// `face` of the chunk's tables as their rows in LDS stand (k_observe's expression; envi.py:87-96,165-217).  Per table, next
+// to the rows: the row of every plane kind + the two fractions (lane i = table i), then lane-parallel over the elements.
+__device__ __attribute__((noinline)) void face_phase(uint4* srow, int ntab, int lane, float4* face, int variant, int64_t t0) {
+  uint4* side = srow + 16 * DDZ_NFIELDS;
+  if (lane < ntab) {
+    const uint8_t* rb = (const uint8_t*)(srow + lane * DDZ_NFIELDS);
+    uint32_t frole = rb[DDZ_F_META * 16];
+    if (frole > 2) frole = 0;
+    const uint32_t fm1 = frole == 0 ? 2 : frole - 1, fp1 = frole == 2 ? 0 : frole + 1;
+    const int n1 = rb[(DDZ_F_HAND0 + fp1) * 16 + 15], n2 = rb[(DDZ_F_HAND0 + fm1) * 16 + 15];
+    const float f1 = n1 + n2 > 0 ? (float)n1 / (float)(n1 + n2) : 0.f, f2 = n1 + n2 > 0 ? (float)n2 / (float)(n1 + n2) : 0.f;
+    side[lane] = make_uint4((DDZ_F_HAND0 + frole) | (uint32_t)DDZ_F_TAKEN << 8 | (DDZ_F_HIST0 + fm1) << 16 | (DDZ_F_HIST0 + frole) << 24,
+                            (DDZ_F_HIST0 + fp1) | (DDZ_F_RECENT0 + fm1) << 8 | (DDZ_F_RECENT0 + fp1) << 16,
+                            __float_as_uint(f1), __float_as_uint(f2));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (variant == 0) face_chunk<4, 0x8710ull>(srow, side, ntab, face + t0 * (4 * 15), lane);
+  else if (variant == 1) face_chunk<7, 0x8743210ull>(srow, side, ntab, face + t0 * (7 * 15), lane);
+  else if (variant == 2) face_chunk<9, 0x876543210ull>(srow, side, ntab, face + t0 * (9 * 15), lane);
+  else face_chunk<6, 0x876510ull>(srow, side, ntab, face + t0 * (6 * 15), lane);
+}
+
+// Round-2b layout: the decode / selection / apply of a chunk of up to SLAB_CH tables is ONE lane-parallel pass (lane i
+// = table t0 + i) over the chunk's state rows staged in the wave's LDS buffer -- the staging list of the list code,
+// idle in this phase -- instead of one wave-wide pass per table; only the deal of a finished game, the wave-parallel
+// list search of ROWS / IDS and the lists of the new states remain per-table work.
+constexpr int SLAB_CH = 16;  // 16 tables x 11 rows x 16 B = 2,816 B <= the 4,000-byte staging list of a wave
+static_assert((SLAB_CH * DDZ_NFIELDS + SLAB_CH) * 16 <= STAGE_CAP * 8 && SLAB_CH == 16, "chunk rows + face side records must fit the staging list");
+
 template <int MODE, bool IDS>
 __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
 #ifdef DDZ_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
   __shared__ HotTabT<false> hot;
-  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
+  __shared__ __attribute__((aligned(16))) uint64_t s_stage[WPB][STAGE_CAP];
   __shared__ uint16_t s_svl[WPB][STAGE_CAP];
   __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
-  __shared__ uint4 s_face[MODE == STEP_Q ? WPB : 1][12];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
-  const int64_t t0 = wave * a.tpw;
-  const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;
-  // every independent global load of the prologue is in flight before anything waits
-  uint4 Rnext = make_uint4(0, 0, 0, 0);
-  if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + t0 * STATE_ROW_BYTES))[lane];
-  int cnt_l = 0;          // lane i: size of the current list of table t0 + i
-  int32_t sel_l = -1;     // lane i: CHOICE index / IDS action id of table t0 + i
-  uint4 pre_row = make_uint4(0, 0, 0, 0);  // CHOICE: lane i prefetches the selected row of table t0 + i ...
+  const int64_t tw0 = wave * a.tpw;
+  const int nw = tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0;  // tables of this wave
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
-  if (lane < ntab) {
-    if (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) sel_l = ((const int32_t*)a.sel)[t0 + lane];
-    cnt_l = a.counts[t0 + lane];
-    if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
-  }
-  if (MODE == STEP_Q) {
-    // the (epsilon-)greedy arg-max of DQNFirst (dqn.py:50-71) over each table's list, as k_select: the 64 lanes read
-    // the table's values coalesced, a butterfly keeps (larger value, smaller index); lane i keeps table t0 + i's index
-    for (int i = 0; i < ntab; ++i) {
-      const int A = (int)rl((uint32_t)cnt_l, i);
-      const float* qrow = (const float*)a.sel + (t0 + i) * a.stride;
+  constexpr bool SEARCH = MODE == DDZ_STEP_ROWS || MODE == DDZ_STEP_IDS;
+  constexpr bool DRAWS = MODE == DDZ_STEP_RANDOM || MODE == DDZ_STEP_IDS;
+  uint64_t* stage = s_stage[wv];
+  uint16_t* svl = s_svl[wv];
+  uint16_t* sid = s_sid[IDS ? wv : 0];
+  uint4* srow = (uint4*)stage;  // [SLAB_CH][11]: the chunk's state rows while no list is being staged
+  const FastLanes fl = fast_lanes(lane);
+  const uint32_t LEAD = mk_info(EMPTY, 0, 1);
+  int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
+  int64_t s_rows = 0;
+  const bool face_first = !((wv >> 2) & 1);  // waves wv and wv + 4 share a SIMD
+  for (int c0 = 0; c0 == 0 || c0 < nw; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
+    const int64_t t0 = tw0 + c0;
+    const int ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
+    const int nrows = ntab * DDZ_NFIELDS;
+    const bool valid = lane < ntab;
+    const int64_t t = t0 + lane;  // the table of this lane in the lane-parallel phases
+    // ---- every independent global load of the chunk is in flight before anything waits
+    uint4* sp = (uint4*)(a.state + t0 * STATE_ROW_BYTES);
+    uint4 R0 = make_uint4(0, 0, 0, 0), R1 = R0, R2 = R0;
+    if (lane < nrows) R0 = sp[lane];
+    if (64 + lane < nrows) R1 = sp[64 + lane];
+    if (128 + lane < nrows) R2 = sp[128 + lane];
+    int cnt_l = 0;       // size of the current list
+    int32_t sel_l = -1;  // CHOICE index / IDS action id
+    uint4 c = make_uint4(0, 0, 0, 0);  // the selected row
+    if (valid) {
+      if (MODE == DDZ_STEP_CHOICE || MODE == DDZ_STEP_IDS) sel_l = ((const int32_t*)a.sel)[t];
+      if (MODE == DDZ_STEP_ROWS) c = ((const uint4*)a.sel)[t];
+      cnt_l = a.counts[t];
+      if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
+    }
+    if (c0 == 0) hot_fill<TB>(hot);
+    if (MODE == STEP_Q) {
+      // the (epsilon-)greedy arg-max of DQNFirst (dqn.py:50-71) over each table's list, as k_select: 4 lanes per table
+      // (lane 4i + s reads entries s, s + 4, ...), a 2-step butterfly keeps (larger value, smaller index)
+      static_assert(SLAB_CH * 4 == 64, "4 lanes per table of the chunk");
+      const int g = lane >> 2;
+      int Ag = 0;
+      if (g < ntab) {
+        Ag = a.counts[t0 + g];
+        if (Ag < 0 || Ag > a.stride) Ag = 0;
+      }
+      const float* qrow = (const float*)a.sel + (t0 + g) * a.stride;
       int best = 0x7FFFFFFF;
       float bq = 0.f;
-      for (int j = lane; j < A; j += 64) {
-        const float v = qrow[j];
-        if (j == 0 || (v == v && (best == 0x7FFFFFFF || v > bq))) { bq = v; best = j; }
+      for (int j0 = lane & 3; j0 < Ag; j0 += 16) {  // four loads in flight per trip
+        const float v0 = qrow[j0];
+        const float v1 = j0 + 4 < Ag ? qrow[j0 + 4] : 0.f;
+        const float v2 = j0 + 8 < Ag ? qrow[j0 + 8] : 0.f;
+        const float v3 = j0 + 12 < Ag ? qrow[j0 + 12] : 0.f;
+        if (j0 == 0 || (v0 == v0 && (best == 0x7FFFFFFF || v0 > bq))) { bq = v0; best = j0; }
+        if (j0 + 4 < Ag && v1 == v1 && (best == 0x7FFFFFFF || v1 > bq)) { bq = v1; best = j0 + 4; }
+        if (j0 + 8 < Ag && v2 == v2 && (best == 0x7FFFFFFF || v2 > bq)) { bq = v2; best = j0 + 8; }
+        if (j0 + 12 < Ag && v3 == v3 && (best == 0x7FFFFFFF || v3 > bq)) { bq = v3; best = j0 + 12; }
       }
 #pragma unroll
-      for (int dd = 1; dd < 64; dd <<= 1) {
+      for (int dd = 1; dd < 4; dd <<= 1) {
         const float oq = __shfl_xor(bq, dd);
         const int ob = __shfl_xor(best, dd);
         const bool have = best != 0x7FFFFFFF, ohave = ob != 0x7FFFFFFF;
         if (ohave && (!have || (ob < best ? !(bq > oq) : (oq > bq)))) { bq = oq; best = ob; }
       }
-      if (A <= 0) best = -1;
-      if (a.thr && A > 0) {
-        const uint4 meta = *(const uint4*)(a.state + (t0 + i) * STATE_ROW_BYTES + DDZ_F_META * 16);
-        const uint64_t g_ = a.gid_base + (uint64_t)(t0 + i);
+      sel_l = __shfl(best, (lane & (SLAB_CH - 1)) * 4);  // lane i < 16: the index of table t0 + i
+      if (cnt_l <= 0) sel_l = -1;
+      if (a.thr && valid && cnt_l > 0) {
+        const uint4 meta = *(const uint4*)(a.state + t * STATE_ROW_BYTES + DDZ_F_META * 16);
+        const uint64_t g_ = a.gid_base + (uint64_t)t;
         const uint4 dr = philox4x32_10(make_uint4((uint32_t)g_, (uint32_t)(g_ >> 32), meta.z, (3u << 16) | (meta.y & 0xFFFF)), a.k0, a.k1);
-        if ((uint64_t)dr.x < a.thr) best = (int)__umulhi(dr.y, (uint32_t)A);
+        if ((uint64_t)dr.x < a.thr) sel_l = (int)__umulhi(dr.y, (uint32_t)cnt_l);
       }
-      if (lane == i) sel_l = best;
+      if (a.choice_out && valid) a.choice_out[t] = sel_l;
     }
-    if (a.choice_out && lane < ntab) a.choice_out[t0 + lane] = sel_l;
-  }
-  if (BYIDX && lane < ntab && sel_l >= 0 && sel_l < a.stride) pre_row = a.rows[(t0 + lane) * a.stride + sel_l];
-  hot_fill<TB>(hot);
-  __syncthreads();
-  TACC(0);
-  // ... and packs / classifies it (lane-parallel: the scalar unit is the bottleneck of this kernel)
-  uint32_t pre_info = 0;  // category | value << 8 | len << 16 | number of cards << 24
-  if (BYIDX) {
-    if (sel_l < 0 || sel_l >= cnt_l) sel_l = -1;
-    const uint64_t pn = pack_row(pre_row);
-    pre_info = info_of_row(pn, (int)(pre_row.w >> 24)) | ((uint32_t)nib_sum(pn) << 24);
-  }
-  uint64_t* stage = s_stage[wv];
-  uint16_t* svl = s_svl[wv];
-  uint16_t* sid = s_sid[IDS ? wv : 0];
-  const FastLanes fl = fast_lanes(lane);
-  int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
-  int64_t s_rows = 0;
-  uint32_t out_l = 0;  // lane i: done | reward << 8 | illegal << 16 of table t0 + i; n_l: the size of its new list
-  int n_l = 0;
-  for (int i = 0; i < ntab; ++i) {
-    const int64_t t = t0 + i;
-    uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
-    uint4 R = Rnext;  // lane f < 11 holds row f of the table
-    if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
-    // ---- decode, lane-parallel: every lane packs and classifies its own row
-    const uint64_t P = pack_row(R);
-    const uint32_t infoL = info_of_row(P, (int)((R.w >> 24) & 15));   // meaningful on the recent-handout rows
-    const uint32_t nz = (uint32_t)__ballot(P != 0);                    // bit f: row f holds cards
-    const uint32_t mx = rl(R.x, DDZ_F_META), my = rl(R.y, DDZ_F_META), mz = rl(R.z, DDZ_F_META);
-    int role = mx & 0xFF;
+    int idx = -1;  // list index of the move, -1 = none / not in the list
+    if (BYIDX) {
+      idx = (sel_l >= 0 && sel_l < cnt_l) ? sel_l : -1;
+      if (idx >= 0) c = a.rows[t * a.stride + idx];
+    }
+    // ---- the chunk's rows into LDS
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < nrows) srow[lane] = R0;
+    if (64 + lane < nrows) srow[64 + lane] = R1;
+    if (128 + lane < nrows) srow[128 + lane] = R2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TACC(0);
+    // ---- decode, one table per lane
+    uint4* tr = srow + (valid ? lane : 0) * DDZ_NFIELDS;
+    const uint4 M = tr[DDZ_F_META];
+    int role = M.x & 0xFF;
     if (role > 2) role = 0;  // never index outside the table on a corrupted import
-    bool is_done = (mx >> 8) & 0xFF;
-    const bool dealt = (my >> 16) & 0xFF;
-    uint32_t ply = my & 0xFFFF, episode = mz;
+    const bool is_done = (M.x >> 8) & 0xFF;
+    const bool dealt = (M.y >> 16) & 0xFF;
+    const uint32_t ply = M.y & 0xFFFF, episode = M.z;
     const uint64_t gid = a.gid_base + (uint64_t)t;
-    const bool active = dealt && !is_done;
+    const bool active = valid && dealt && !is_done;
     const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+    const uint4 Hr = tr[DDZ_F_HAND0 + role];
     // the combo the current actor has to beat (envi.py:103-109): previous player's handout, else the one before
-    const int lsrc = ((nz >> (DDZ_F_RECENT0 + rm1)) & 1u) ? DDZ_F_RECENT0 + rm1 : DDZ_F_RECENT0 + rp1;
-    const uint32_t cur_info = ((nz >> lsrc) & 1u) ? rl(infoL, lsrc) : mk_info(EMPTY, 0, 1);
-    const int A = (int)rl((uint32_t)cnt_l, i);
+    const uint4 Ra = tr[DDZ_F_RECENT0 + rm1], Rb = tr[DDZ_F_RECENT0 + rp1];
+    const uint64_t Pa = pack_row(Ra), Pb = pack_row(Rb);
+    const bool useA = Pa != 0;
+    const uint64_t Pl = useA ? Pa : Pb;
+    const uint32_t cur_info = Pl ? info_of_row(Pl, (int)(((useA ? Ra.w : Rb.w) >> 24) & 15)) : LEAD;
+    const int A = cnt_l;
     const bool frozen = !active || A <= 0;
-    // ---- selection
-    int idx = -1;
-    uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, the same value in every lane
-    uint32_t cinfo = 0;                 // its category | value << 8 | len << 16 | number of cards << 24
-    const int32_t sel_i = (BYIDX || MODE == DDZ_STEP_IDS) ? (int32_t)rl((uint32_t)sel_l, i) : 0;
-    if (!frozen) {
-      if (BYIDX) {
-        idx = sel_i;
-        if (idx >= 0) {
-          c = make_uint4(rl(pre_row.x, i), rl(pre_row.y, i), rl(pre_row.z, i), rl(pre_row.w, i));
-          cinfo = rl(pre_info, i);
+    // ---- selection: every mode ends as (idx, c) per lane
+    if (!BYIDX) {
+      bool draw = MODE == DDZ_STEP_RANDOM;
+      if (MODE == DDZ_STEP_IDS) draw = sel_l == -1;
+      if (DRAWS && draw && !frozen) {  // random.choice(actions), envi.py:83
+        const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
+        idx = (int)__umulhi(d.x, (uint32_t)A);
+      }
+      if (SEARCH) {  // wave-parallel search of a table's list for the wanted counts, table after table
+        constexpr int NIDS = DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS;
+        bool need = !frozen && !draw;
+        if (MODE == DDZ_STEP_IDS) {
+          if (sel_l < 0 || sel_l >= NIDS) need = false;  // no such action: not in any list
+          c = row_of_id(need ? sel_l : 0);
         }
-      } else {
-        if (MODE == DDZ_STEP_RANDOM || (MODE == DDZ_STEP_IDS && sel_i == -1)) {  // random.choice(actions), envi.py:83
-          const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (2u << 16) | ply), a.k0, a.k1);
-          idx = (int)__umulhi(rfl(d.x), (uint32_t)A);
-        } else {  // wave-parallel search of the list for the wanted counts
-          constexpr int NIDS = DDZ_NUM_ACTIONS + 24 * DDZ_NATIVE_JOKER_KICKERS;
-          const bool id_ok = MODE != DDZ_STEP_IDS || (sel_i >= 0 && sel_i < NIDS);
-          const uint4 want = MODE == DDZ_STEP_IDS ? row_of_id(id_ok ? sel_i : 0) : ((const uint4*)a.sel)[t];
-          for (int j0 = 0; j0 < A && idx < 0 && id_ok; j0 += 64) {
+        uint64_t nm = __ballot(need);
+        while (nm) {
+          const int i = __builtin_ctzll(nm);
+          nm &= nm - 1;
+          const uint4 want = make_uint4(rl(c.x, i), rl(c.y, i), rl(c.z, i), rl(c.w, i));
+          const int Ai = (int)rl((uint32_t)A, i);
+          const uint4* lrow = a.rows + (t0 + i) * a.stride;
+          int found = -1;
+          for (int j0 = 0; j0 < Ai && found < 0; j0 += 64) {
             bool hit = false;
-            if (j0 + lane < A) {
-              const uint4 r = a.rows[t * a.stride + j0 + lane];
+            if (j0 + lane < Ai) {
+              const uint4 r = lrow[j0 + lane];
               hit = r.x == want.x && r.y == want.y && r.z == want.z && ((r.w ^ want.w) & 0x00FFFFFFu) == 0;
             }
             const uint64_t hb = __ballot(hit);
-            if (hb) idx = j0 + __builtin_ctzll(hb);
+            if (hb) found = j0 + __builtin_ctzll(hb);
           }
-        }
-        if (idx >= 0) {  // every lane loads the same row: it stays in vector registers, no scalar unpacking
-          const uint4 r = a.rows[t * a.stride + idx];
-          const uint64_t pn = pack_row(r);
-          c = make_uint4(rfl(r.x), rfl(r.y), rfl(r.z), rfl(r.w));
-          cinfo = rfl(info_of_row(pn, (int)(r.w >> 24)) | ((uint32_t)nib_sum(pn) << 24));
+          if (lane == i) idx = found;
         }
       }
+      if (idx >= 0) c = a.rows[t * a.stride + idx];  // the listed row carries the category byte
+    }
+    uint32_t cinfo = 0;  // category | value << 8 | len << 16 | number of cards << 24 of the move
+    if (idx >= 0) {
+      const uint64_t pn = pack_row(c);
+      cinfo = info_of_row(pn, (int)(c.w >> 24)) | ((uint32_t)nib_sum(pn) << 24);
     }
     TACC(2);
     // ---- apply (envi.py:38-43 _update + native step), outputs, trajectory record
     uint4 tr0 = make_uint4(0, 0, 0, 0);
     uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)A & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
     uint32_t o_done = is_done, o_illegal = 0, o_reward = 0;
-    bool live = active;                                        // is there a list to write afterwards
-    uint64_t qhand = 0;                                        // ... and for which (hand, combo to beat)
+    bool live = active;        // is there a list to write afterwards
+    uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
     uint32_t qinfo = cur_info;
-    bool changed = false;
+    bool changed = false, won = false;
     if (frozen) {
       tr1.x |= (uint32_t)is_done << 8 | 2u << 24;
-      if (active) qhand = rl64(P, DDZ_F_HAND0 + role);  // a live table whose list was reported empty: write it afresh
+      if (active) qhand = pack_row(Hr);  // a live table whose list was reported empty: write it afresh
     } else if (idx < 0) {  // not in the list: table untouched, flagged; its list is written again as it was
       o_done = 0; o_illegal = 1;
       tr1.x |= 1u << 24;
-      qhand = rl64(P, DDZ_F_HAND0 + role);
+      qhand = pack_row(Hr);
     } else {
       changed = true;
       const uint32_t ncards = cinfo >> 24;
       const uint32_t cw3 = c.w & 0x00FFFFFFu;
-      const uint32_t left_before = rl(R.w, DDZ_F_HAND0 + role) >> 24;
-      // byte-wise: every byte of the hand >= the row's byte, so no borrow/carry crosses a byte
-      if (lane == DDZ_F_HAND0 + role) {
-        R.x -= c.x; R.y -= c.y; R.z -= c.z; R.w -= cw3 + (ncards << 24);
-      } else if (lane == DDZ_F_HIST0 + role || lane == DDZ_F_TAKEN) {
-        R.x += c.x; R.y += c.y; R.z += c.z; R.w += cw3;
-      } else if (lane == DDZ_F_RECENT0 + role) {
-        R = c;
-      }
-      const bool won = left_before == ncards;
+      won = (Hr.w >> 24) == ncards;
       o_reward = won ? (role == 1 ? 0xFFu : 1u) : 0u;  // rule_play.py:14: -1 lord won, +1 farmers
       o_done = won;
-      s_ply += 1; s_eps += won; s_lord += (won && role == 1); s_up += (won && role == 0);
       tr0 = c;
       tr1.x |= (uint32_t)won << 8 | o_reward << 16;
       tr1.w = (uint32_t)idx;
-      ply += 1;
-      if (won && a.auto_reset) {
-        episode += 1;
-        uint64_t h0, h1, h2;
-        deal_wave(gid, episode, a.k0, a.k1, lane, h0, h1, h2);
-        R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
-            : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
-        qhand = h1; qinfo = mk_info(EMPTY, 0, 1);  // the lord leads
-      } else {
-        if (lane == DDZ_F_META)
-          R = make_uint4((uint32_t)rp1 | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) | (o_reward << 24),
-                         (my & 0xFFFF0000u) | (ply & 0xFFFF), mz, R.w);
+      if (!(won && a.auto_reset)) {
+        // byte-wise: every byte of the hand >= the row's byte, so no borrow/carry crosses a byte
+        tr[DDZ_F_HAND0 + role] = make_uint4(Hr.x - c.x, Hr.y - c.y, Hr.z - c.z, Hr.w - (cw3 + (ncards << 24)));
+        const uint4 Hi = tr[DDZ_F_HIST0 + role], Tk = tr[DDZ_F_TAKEN];
+        tr[DDZ_F_HIST0 + role] = make_uint4(Hi.x + c.x, Hi.y + c.y, Hi.z + c.z, Hi.w + cw3);
+        tr[DDZ_F_TAKEN] = make_uint4(Tk.x + c.x, Tk.y + c.y, Tk.z + c.z, Tk.w + cw3);
+        tr[DDZ_F_RECENT0 + role] = c;
+        tr[DDZ_F_META] = make_uint4((uint32_t)rp1 | (won ? 1u << 8 : 0u) | ((won ? (uint32_t)role : 0xFFu) << 16) | (o_reward << 24),
+                                    (M.y & 0xFFFF0000u) | ((ply + 1) & 0xFFFF), M.z, M.w);
         live = !won;
         // the next actor (lord -> down -> up, game.py:173-181) has to beat this ply's combo, or -- after a pass -- the
         // previous player's: its hand is untouched by this ply
-        qhand = rl64(P, DDZ_F_HAND0 + rp1);
-        if (ncards) qinfo = cinfo & 0x00FFFFFFu;
-        else qinfo = ((nz >> (DDZ_F_RECENT0 + rm1)) & 1u) ? rl(infoL, DDZ_F_RECENT0 + rm1) : mk_info(EMPTY, 0, 1);
+        qhand = pack_row(tr[DDZ_F_HAND0 + rp1]);
+        qinfo = ncards ? (cinfo & 0x00FFFFFFu) : (useA ? cur_info : LEAD);
       }
     }
-    if (lane == i) out_l = (o_done & 0xFF) | ((o_reward & 0xFF) << 8) | ((o_illegal & 0xFF) << 16);
-    if (a.traj && lane < 2) a.traj[2 * t + lane] = sel4(lane == 0, tr0, tr1);
-    if (changed && lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
-    TACC(3);
-    // ---- the list of the (new) state, straight into the table's slab
-    int n = 0;
-    if (live) n = slab_list<IDS>(qhand, rfl(qinfo), t * a.stride, a.stride, a.rows, a.ids, stage, svl, sid, hot, lane, fl, a.status);
-    if (lane == i) n_l = n;
-    s_rows += n;
-    if (MODE == STEP_Q && a.face) {
-      // `face` of the table as it now stands (k_observe's expression; envi.py:87-96,165-217): the wave's rows go through
-      // LDS so that lane e can read the byte of (plane, rank) = (e / 15, e % 15)
-      uint8_t* rb = (uint8_t*)s_face[wv];
-      if (lane < DDZ_NFIELDS) s_face[wv][lane] = R;
-      __builtin_amdgcn_wave_barrier();
-      const int v_ = a.face_variant;
-      const int P = v_ == 0 ? 4 : v_ == 1 ? 7 : v_ == 2 ? 9 : 6;
-      const uint64_t KINDS = v_ == 0 ? 0x8710ull : v_ == 1 ? 0x8743210ull : v_ == 2 ? 0x876543210ull : 0x876510ull;
-      int frole = rb[DDZ_F_META * 16];
-      if (frole > 2) frole = 0;
-      const int fm1 = frole == 0 ? 2 : frole - 1, fp1 = frole == 2 ? 0 : frole + 1;
-      const int n1 = rb[(DDZ_F_HAND0 + fp1) * 16 + 15], n2 = rb[(DDZ_F_HAND0 + fm1) * 16 + 15];
-      for (int e = lane; e < P * 15; e += 64) {
-        const int pl = e / 15, ri = e - pl * 15;
-        const int kind = (int)((KINDS >> (4 * pl)) & 15);
-        float4 v;
-        if (kind < 7) {
-          const int f = kind == 0 ? DDZ_F_HAND0 + frole : kind == 1 ? DDZ_F_TAKEN
-                      : kind == 2 ? DDZ_F_HIST0 + fm1 : kind == 3 ? DDZ_F_HIST0 + frole
-                      : kind == 4 ? DDZ_F_HIST0 + fp1 : kind == 5 ? DDZ_F_RECENT0 + fm1 : DDZ_F_RECENT0 + fp1;
-          const int c_ = rb[f * 16 + ri];
-          v = make_float4(c_ > 0 ? 1.f : 0.f, c_ > 1 ? 1.f : 0.f, c_ > 2 ? 1.f : 0.f, c_ > 3 ? 1.f : 0.f);
-        } else {
-          const int known = rb[(DDZ_F_HAND0 + frole) * 16 + ri] + rb[DDZ_F_TAKEN * 16 + ri], total = ri < 13 ? 4 : 1;
-          const float fr = n1 + n2 > 0 ? (float)(kind == 7 ? n1 : n2) / (float)(n1 + n2) : 0.f;
-          v = make_float4((0 >= known && 0 < total) ? fr : 0.f, (1 >= known && 1 < total) ? fr : 0.f,
-                          (2 >= known && 2 < total) ? fr : 0.f, (3 >= known && 3 < total) ? fr : 0.f);
-        }
-        store_stream(&a.face[t * (P * 15) + e], v);
+    {
+      const uint64_t chm = __ballot(changed), wm = __ballot(changed && won);
+      s_ply += __builtin_popcountll(chm);
+      s_eps += __builtin_popcountll(wm);
+      s_lord += __builtin_popcountll(wm & __ballot(role == 1));
+      s_up += __builtin_popcountll(wm & __ballot(role == 0));
+      if (a.traj && valid) {
+        a.traj[2 * t] = tr0;
+        a.traj[2 * t + 1] = tr1;
       }
+      // finished games with auto-reset: the next episode's deal (wave-wide), the lord leads
+      uint64_t wr = a.auto_reset ? wm : 0ull;
+      while (wr) {
+        const int i = __builtin_ctzll(wr);
+        wr &= wr - 1;
+        const uint32_t ep = rl(episode, i) + 1u;
+        uint64_t h0, h1, h2;
+        deal_wave(a.gid_base + (uint64_t)(t0 + i), ep, a.k0, a.k1, lane, h0, h1, h2);
+        if (lane < DDZ_NFIELDS)
+          srow[i * DDZ_NFIELDS + lane] = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+                                         : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, ep, 0) : make_uint4(0, 0, 0, 0);
+        if (lane == i) { qhand = h1; qinfo = LEAD; }
+      }
+      // the rows of the tables that moved, back to the state: coalesced 16-byte stores
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (lane < nrows && ((chm >> (lane / DDZ_NFIELDS)) & 1)) sp[lane] = srow[lane];
+      if (64 + lane < nrows && ((chm >> ((64 + lane) / DDZ_NFIELDS)) & 1)) sp[64 + lane] = srow[64 + lane];
+      if (128 + lane < nrows && ((chm >> ((128 + lane) / DDZ_NFIELDS)) & 1)) sp[128 + lane] = srow[128 + lane];
+    }
+    TACC(3);
+    if (c0 == 0) __syncthreads();  // the hot records are in LDS
+    if (MODE == STEP_Q && a.face && face_first) {
+      face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
+      TACC(6);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the rows in LDS are dead from here: the buffer is the staging list again
+    // ---- the lists of the (new) states, straight into the tables' slabs
+    int n_l = 0;
+    uint64_t lv = __ballot(live);
+    while (lv) {
+      const int i = __builtin_ctzll(lv);
+      lv &= lv - 1;
+      const int n = slab_list<IDS>(rl64(qhand, i), rl(qinfo, i), (t0 + i) * a.stride, a.stride, a.rows, a.ids, stage, svl, sid,
+                                   hot, lane, fl, a.status);
+      if (lane == i) n_l = n;
+      s_rows += n;
+    }
+    if (MODE == STEP_Q && a.face && !face_first) {
+      // this half of the waves writes `face` after its lists, from the rows it stored before them, so that at any time
+      // some waves of a SIMD are in the HBM-bound phase and the others in the issue-bound one
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane < nrows) srow[lane] = sp[lane];
+      if (64 + lane < nrows) srow[64 + lane] = sp[64 + lane];
+      if (128 + lane < nrows) srow[128 + lane] = sp[128 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      TACC(6);
+    }
+    if (valid) {  // the per-table outputs: consecutive addresses, one store each
+      a.counts[t] = n_l;
+      if (a.done) a.done[t] = (uint8_t)o_done;
+      if (a.reward) a.reward[t] = (int8_t)o_reward;
+      if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
     }
     TACC(4);
   }
 #ifdef DDZ_STAMP
-  if (g_stamps && lane == 0 && ntab > 0) {
-    tacc[5] = ntab;
-    for (int q = 0; q < 8; ++q) g_stamps[16 * t0 + q] = tacc[q];
+  if (g_stamps && lane == 0 && nw > 0) {
+    tacc[5] = nw;
+    for (int q = 0; q < 8; ++q) g_stamps[16 * tw0 + q] = tacc[q];
   }
 #endif
-  if (lane < ntab) {  // the per-table outputs of the wave's tables: consecutive addresses, one store each
-    a.counts[t0 + lane] = n_l;
-    if (a.done) a.done[t0 + lane] = (uint8_t)out_l;
-    if (a.reward) a.reward[t0 + lane] = (int8_t)(out_l >> 8);
-    if (a.illegal) a.illegal[t0 + lane] = (uint8_t)(out_l >> 16);
-  }
-  if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
+  if (nw > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
   }

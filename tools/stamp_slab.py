@@ -44,4 +44,20 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
         per = s[:, k] / (ntab if k >= 2 else 1)
         print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}")
     print(f"  total per wave mean {s[:, :5].sum(1).mean():8.0f} cycles")
+    # the fused policy iteration (ddz_policy_step_slab): arg-max in the prologue, `face` between apply and lists
+    q = torch.rand((T, env.slab_stride), dtype=torch.float32, device="cuda")
+    face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device="cuda")
+    for _ in range(10):
+        env.policy_step_slab(q, face_variant=3, face_out=face, auto_reset=True)
+    buf.zero_()
+    assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
+    env.policy_step_slab(q, face_variant=3, face_out=face, auto_reset=True)
+    torch.cuda.synchronize()
+    assert raw.ddz_debug_set_stamps(None) == 0
+    s = buf.cpu().numpy().astype(np.float64)
+    s = s[s[:, 5] > 0]
+    ntab = s[:, 5]
+    print(f"T={T} fused: per table: prologue+argmax {np.mean(s[:, 0] / ntab):.0f}  decode {np.mean(s[:, 2] / ntab):.0f}  "
+          f"apply {np.mean(s[:, 3] / ntab):.0f}  face {np.mean(s[:, 6] / ntab):.0f}  lists {np.mean(s[:, 4] / ntab):.0f}  "
+          f"total per wave {s[:, [0, 2, 3, 4, 6]].sum(1).mean():.0f}")
     del env
