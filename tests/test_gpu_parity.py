@@ -1016,3 +1016,65 @@ def test_slab_to_csr_equals_legal(pkg):
     assert int(off[-1].item()) == total > 2400 and env.status() & 2
     off2, rows2, ids2 = env.legal()
     assert torch.equal(rows[:2400], rows2[:2400]) and torch.equal(ids[:2400], ids2[:2400])
+
+
+@pytest.mark.parametrize("tpw", [1, 5, 16, 23, 40])
+def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
+    """k_slab handles a wave's tables in lane-parallel chunks of 16: every chunking (one table per wave, a partial chunk,
+    exactly one, 16 + 7, 16 + 16 + 8; the last wave ragged) x every mode (CHOICE, ROWS, IDS with engine draws, RANDOM)
+    against the oracle: lists, done / r / illegal, trajectory records and the full state after every iteration."""
+    import os
+    T, seed = 1003, 40 + tpw
+    rng = np.random.default_rng(seed)
+    old = os.environ.get("DDZ_TPW")
+    os.environ["DDZ_TPW"] = str(tpw)
+    try:
+        env = pkg.BatchedEnv(T, seed=seed, device=_dev())
+    finally:
+        if old is None:
+            os.environ.pop("DDZ_TPW")
+        else:
+            os.environ["DDZ_TPW"] = old
+    ref = oracle.OracleEnv(T, seed=seed)
+    env.reset(); ref.reset()
+    counts, rows, ids = env.legal_slab()
+    traj = torch.zeros((T, 32), dtype=torch.uint8, device=_dev())
+    for it in range(48):
+        roff, rrows, rids = ref.legal()
+        n = np.diff(roff)
+        assert np.array_equal(counts.cpu().numpy(), n)
+        take = np.arange(env.slab_stride)[None, :] < n[:, None]
+        assert np.array_equal(ids.cpu().numpy()[take], rids) and np.array_equal(rows.cpu().numpy()[take], rrows)
+        choice = (rng.random(T) * np.maximum(n, 1)).astype(np.int32)
+        bad = rng.random(T) < 0.04
+        choice[bad] = np.where(rng.random(bad.sum()) < 0.5, -1, n[bad] + rng.integers(0, 3, bad.sum()))
+        ok = (choice >= 0) & (choice < n)
+        auto = it % 6 != 5
+        mode = it % 4
+        if mode == 0:
+            sel, gm, om = choice, pkg.STEP_CHOICE, oracle.STEP_CHOICE
+        elif mode == 1:
+            sel = np.zeros((T, 16), np.int8)
+            sel[ok] = rrows[roff[:-1][ok] + choice[ok]]
+            sel[ok, 15] = 0                                   # the caller's rows carry no category byte
+            sel[~ok, 0] = 7
+            gm, om = pkg.STEP_ROWS, oracle.STEP_ROWS
+        elif mode == 2:
+            sel = np.full(T, 13600, np.int32)                 # no such action
+            sel[ok] = rids[roff[:-1][ok] + choice[ok]]
+            draw = rng.random(T) < 0.3
+            sel[draw] = -1                                    # engine RNG for these tables
+            gm, om = pkg.STEP_IDS, oracle.STEP_IDS
+        else:
+            sel, gm, om = None, pkg.STEP_RANDOM, oracle.STEP_RANDOM
+        done, r, ill = env.step_slab(None if sel is None else torch.from_numpy(sel).to(_dev()), gm, auto_reset=auto, traj=traj)
+        rdone, rr, rill, rtraj = ref.step(om, sel, auto_reset=auto, want_traj=True)
+        assert np.array_equal(done.cpu().numpy(), rdone) and np.array_equal(r.cpu().numpy(), rr), (tpw, it)
+        assert np.array_equal(ill.cpu().numpy(), rill), (tpw, it)
+        assert np.array_equal(traj.cpu().numpy(), rtraj), (tpw, it)
+        assert np.array_equal(env.state_export().cpu().numpy(), ref.state), (tpw, it)
+        if it % 12 == 11:
+            m = (env.field(10)[:, 1] != 0)
+            env.reset(mask=m); ref.reset(m.cpu().numpy().astype(np.uint8))
+            counts, rows, ids = env.legal_slab()
+    assert env.status() == 0
