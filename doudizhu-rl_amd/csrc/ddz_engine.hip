@@ -1147,6 +1147,7 @@ struct SlabArgs {
   int32_t* choice_out;  // [T] the selected list indices, or null
   float4* face;         // [T][P][15] `face` of the NEW states, or null
   int face_variant;
+  int coop;             // tpw == 1: wave 0 of a block runs the lane-parallel phases of the block's tables
 };
 constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
 
@@ -1282,8 +1283,15 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
-  const int64_t tw0 = wave * a.tpw;
-  const int nw = tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0;  // tables of this wave
+  // one table per wave (T <= 4096): the lane-parallel phases of the block's 8 tables are run by wave 0 alone (otherwise
+  // 16 waves per CU each issue them for ONE useful lane), the 8 waves then write one list each
+  const bool coop = a.coop != 0;
+  const int64_t tb0 = (int64_t)blockIdx.x * WPB;  // coop: the block's tables
+  const int cn = coop ? (tb0 < a.T ? (int)(a.T - tb0 < WPB ? a.T - tb0 : WPB) : 0) : 0;
+  const int64_t tw0 = coop ? tb0 : wave * a.tpw;
+  const int nw = coop ? (wv == 0 ? cn : 0)
+                      : (tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0);  // tables of this wave's lane-parallel phases
+  __shared__ uint4 s_share[WPB];  // coop: (hand, combo to beat, live) of the block's tables for the list phase
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
   constexpr bool SEARCH = MODE == DDZ_STEP_ROWS || MODE == DDZ_STEP_IDS;
   constexpr bool DRAWS = MODE == DDZ_STEP_RANDOM || MODE == DDZ_STEP_IDS;
@@ -1318,6 +1326,11 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
     }
     if (c0 == 0) hot_fill<TB>(hot);
+    uint32_t o_done = 0, o_illegal = 0, o_reward = 0;
+    bool live = false;         // is there a list to write afterwards
+    uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
+    uint32_t qinfo = 0;
+    if (ntab > 0) {  // (wave-uniform)
     if (MODE == STEP_Q) {
       // the (epsilon-)greedy arg-max of DQNFirst (dqn.py:50-71) over each table's list, as k_select: 4 lanes per table
       // (lane 4i + s reads entries s, s + 4, ...), a 2-step butterfly keeps (larger value, smaller index)
@@ -1437,10 +1450,9 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     // ---- apply (envi.py:38-43 _update + native step), outputs, trajectory record
     uint4 tr0 = make_uint4(0, 0, 0, 0);
     uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)A & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
-    uint32_t o_done = is_done, o_illegal = 0, o_reward = 0;
-    bool live = active;        // is there a list to write afterwards
-    uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
-    uint32_t qinfo = cur_info;
+    o_done = is_done;
+    live = active;
+    qinfo = cur_info;
     bool changed = false, won = false;
     if (frozen) {
       tr1.x |= (uint32_t)is_done << 8 | 2u << 24;
@@ -1505,9 +1517,11 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       if (64 + lane < nrows && ((chm >> ((64 + lane) / DDZ_NFIELDS)) & 1)) sp[64 + lane] = srow[64 + lane];
       if (128 + lane < nrows && ((chm >> ((128 + lane) / DDZ_NFIELDS)) & 1)) sp[128 + lane] = srow[128 + lane];
     }
+    if (coop && valid) s_share[lane] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, live ? 1u : 0u);
+    }  // ntab > 0
     TACC(3);
     if (c0 == 0) __syncthreads();  // the hot records are in LDS
-    if (MODE == STEP_Q && a.face && face_first) {
+    if (MODE == STEP_Q && a.face && face_first && ntab > 0) {
       face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
       TACC(6);
     }
@@ -1515,7 +1529,17 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     __builtin_amdgcn_wave_barrier();  // the rows in LDS are dead from here: the buffer is the staging list again
     // ---- the lists of the (new) states, straight into the tables' slabs
     int n_l = 0;
-    uint64_t lv = __ballot(live);
+    if (coop) {
+      if (wv < cn) {  // this wave's table of the block
+        const uint4 sh = s_share[wv];
+        int n = 0;
+        if (sh.w) n = slab_list<IDS>((uint64_t)rfl(sh.x) | ((uint64_t)rfl(sh.y) << 32), rfl(sh.z), (tb0 + wv) * a.stride, a.stride, a.rows,
+                                     a.ids, stage, svl, sid, hot, lane, fl, a.status);
+        if (lane == 0) a.counts[tb0 + wv] = n;
+        s_rows += n;
+      }
+    }
+    uint64_t lv = coop ? 0ull : __ballot(live);
     while (lv) {
       const int i = __builtin_ctzll(lv);
       lv &= lv - 1;
@@ -1524,7 +1548,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       if (lane == i) n_l = n;
       s_rows += n;
     }
-    if (MODE == STEP_Q && a.face && !face_first) {
+    if (MODE == STEP_Q && a.face && !face_first && ntab > 0) {
       // this half of the waves writes `face` after its lists, from the rows it stored before them, so that at any time
       // some waves of a SIMD are in the HBM-bound phase and the others in the issue-bound one
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1539,7 +1563,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       TACC(6);
     }
     if (valid) {  // the per-table outputs: consecutive addresses, one store each
-      a.counts[t] = n_l;
+      if (!coop) a.counts[t] = n_l;
       if (a.done) a.done[t] = (uint8_t)o_done;
       if (a.reward) a.reward[t] = (int8_t)o_reward;
       if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
@@ -1552,7 +1576,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     for (int q = 0; q < 8; ++q) g_stamps[16 * tw0 + q] = tacc[q];
   }
 #endif
-  if (nw > 0 && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
+  if ((coop ? wv < cn : nw > 0) && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
   }
@@ -2131,6 +2155,7 @@ struct ddz_env {
   int parity;         // which scan buffer describes the current state
   bool counts_valid;
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
+  int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
 };
 
 namespace {
@@ -2266,6 +2291,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->tpw = pick_tpw(T);
   e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
+  e->slab_coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);  // (0: diagnostic, tools/)
   *out = e;
   return DDZ_OK;
 }
@@ -2353,6 +2379,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
+  a.coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)e->nblocks), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
@@ -2387,6 +2414,7 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
+  a.coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);
   const dim3 grid((unsigned)e->nblocks), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);

@@ -9,7 +9,13 @@ env = pkg.BatchedEnv(T, seed=0, want_ids=False)
 env.reset()
 env.legal_slab()
 choice = torch.zeros(T, dtype=torch.int32, device="cuda")
+RANDOM = len(sys.argv) > 3 and sys.argv[3] == "random"  # uniformly random legal moves instead of list entry 0
+if RANDOM:
+    env.rollout_random(40)
+    env.legal_slab()
 for _ in range(N):
+    if RANDOM:
+        choice = (torch.rand(T, device="cuda") * env.counts).to(torch.int32)
     env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
 torch.cuda.synchronize()
 print(env.stats(), env.status())
