@@ -1571,9 +1571,9 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     TACC(4);
   }
 #ifdef DDZ_STAMP
-  if (g_stamps && lane == 0 && nw > 0) {
-    tacc[5] = nw;
-    for (int q = 0; q < 8; ++q) g_stamps[16 * tw0 + q] = tacc[q];
+  if (g_stamps && lane == 0 && (coop ? wv < cn : nw > 0)) {
+    tacc[5] = coop ? 1 : nw;
+    for (int q = 0; q < 8; ++q) g_stamps[16 * (coop ? tb0 + wv : tw0) + q] = tacc[q];
   }
 #endif
   if ((coop ? wv < cn : nw > 0) && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)

@@ -26,9 +26,14 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
     env.reset()
     env.rollout_random(60)
     env.legal_slab()
+    RANDOM = len(sys.argv) > 2 and sys.argv[2] == "random"   # uniformly random legal moves instead of list entry 0
     choice = torch.zeros(T, dtype=torch.int32, device="cuda")
     for _ in range(10):
+        if RANDOM:
+            choice = (torch.rand(T, device="cuda") * env.counts).to(torch.int32)
         env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+    if RANDOM:
+        choice = (torch.rand(T, device="cuda") * env.counts).to(torch.int32)
     buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
     assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
     env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
@@ -42,7 +47,7 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
     print(f"T={T}: {len(s)} waves, {ntab.mean():.1f} tables per wave; s_memtime cycles per wave")
     for k, nm in enumerate(names):
         per = s[:, k] / (ntab if k >= 2 else 1)
-        print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}")
+        print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}  max {per.max():8.0f}")
     print(f"  total per wave mean {s[:, :5].sum(1).mean():8.0f} cycles")
     # the fused policy iteration (ddz_policy_step_slab): arg-max in the prologue, `face` between apply and lists
     q = torch.rand((T, env.slab_stride), dtype=torch.float32, device="cuda")
