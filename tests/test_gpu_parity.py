@@ -428,12 +428,24 @@ def test_select_long_lists_ties_and_nans(pkg, oracle):
         env.reset(); ref.reset()                   # next episode: new 20-card leads
 
 
-@pytest.mark.parametrize("eps,variant,want_ids", [(0.0, 3, True), (0.3, 2, False), (0.0, 0, True), (1.0, 1, True)])
-def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids):
+@pytest.mark.parametrize("eps,variant,want_ids,tpw", [(0.0, 3, True, 1), (0.3, 2, False, 1), (0.0, 0, True, 7), (1.0, 1, True, 16),
+                                                      (0.2, 3, False, 37), (0.0, 2, True, 20)])
+def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids, tpw):
     """ddz_policy_step_slab (select + step + new lists + face in ONE launch) == select_slab -> step_slab -> observe:
-    choices, done / r / illegal, trajectory records, states, lists and `face` bit-identical, every iteration."""
+    choices, done / r / illegal, trajectory records, states, lists and `face` bit-identical, every iteration; one table
+    per wave (wave 0 of a block runs the block's lane-parallel phases) and several chunkings of 16-table chunks (the
+    fused kernel writes `face` before the lists in half of its waves and after them in the other half)."""
+    import os
     T = 3000
-    a = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
+    old = os.environ.get("DDZ_TPW")
+    os.environ["DDZ_TPW"] = str(tpw)
+    try:
+        a = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
+    finally:
+        if old is None:
+            os.environ.pop("DDZ_TPW")
+        else:
+            os.environ["DDZ_TPW"] = old
     b = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
     a.reset(); b.reset()
     a.legal_slab(); b.legal_slab()
