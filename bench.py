@@ -114,8 +114,21 @@ def other_config_legs(pkg, torch, dev):
     out["tables_65536_policy_loop_fused"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
                                              "us_per_iteration": dt / (20 * reps) * 1e6,
                                              "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
-    dt, reps = timed_loop(lambda: [env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True) for _ in range(20)], sync)
-    out["tables_65536_step_slab_only"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6}
+    # the stepping launch alone (uniformly random legal moves drawn in the kernel: every selection is in its list), and
+    # the same with the new lists packed to CSR every iteration (what a ragged NN forward over all legal moves consumes)
+    dt, reps = timed_loop(lambda: [env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True) for _ in range(20)], sync)
+    out["tables_65536_step_slab_only"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6,
+                                          "loop": "step_slab(RANDOM)"}
+
+    def csr_iter():
+        env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
+        env.slab_to_csr(rows_per_table=128)
+
+    dt, reps = timed_loop(lambda: [csr_iter() for _ in range(20)], sync)
+    out["tables_65536_step_slab_csr_lists"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6,
+                                               "loop": "step_slab(RANDOM) + slab_to_csr: offsets / rows / ids as ddz_legal writes them"}
+    env.csr_rows = env.csr_ids = None
+    env._csr_cap = 0
     # (3) configs[3]: farmers played by the rule-based opponent (Env.step_auto), the lord by the random policy
     def auto_iter():
         ids = env.auto_choose(0b101)

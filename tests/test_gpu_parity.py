@@ -954,7 +954,7 @@ def test_bench_contract():
     assert r["issue"] is None or (r["issue"]["bound"] == "valu-issue" and 0 < r["issue"]["frac"] < 1)
     legs = j["configs"]
     for k in ("tables_65536_random_rollout", "tables_65536_policy_loop_slab", "tables_65536_policy_loop_fused", "tables_65536_step_slab_only",
-              "tables_65536_rule_opponent"):
+              "tables_65536_step_slab_csr_lists", "tables_65536_rule_opponent"):
         assert legs[k]["env_steps_per_s"] > 1e6, (k, legs)
     ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
     assert ret["up"] == ret["down"] == -ret["lord"] / 2 and ret["lord"] < -50  # rule farmers beat a random lord
