@@ -1090,3 +1090,43 @@ def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
             env.reset(mask=m); ref.reset(m.cpu().numpy().astype(np.uint8))
             counts, rows, ids = env.legal_slab()
     assert env.status() == 0
+
+
+def test_stepping_calls_are_graph_capturable(pkg):
+    """Every launch of the stepping API goes to the caller's current stream and nothing in it synchronises, so a caller
+    can capture its loop in a hipGraph (torch.cuda.graph) and replay it: 3 replays of 8 captured iterations (observe +
+    select_slab + step_slab, and the fused policy step) == the same 24 iterations issued one by one."""
+    T, K = 777, 8
+    a = pkg.BatchedEnv(T, seed=8, device=_dev())
+    b = pkg.BatchedEnv(T, seed=8, device=_dev())
+    a.reset(); b.reset(); a.legal_slab(); b.legal_slab()
+    q = torch.rand((T, a.slab_stride), dtype=torch.float32, device=_dev())
+    fa = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=_dev())
+    fb = torch.empty_like(fa)
+    ca = torch.empty(T, dtype=torch.int32, device=_dev())
+    cb = torch.empty_like(ca)
+
+    def body(env, face, choice):
+        for k in range(K):
+            if k % 2:
+                env.policy_step_slab(q, 0.25, face_variant=3, face_out=face)
+            else:
+                env.observe(3, out=face)
+                env.select_slab(q, 0.25, out=choice)
+                env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+
+    body(a, fa, ca); body(b, fb, cb)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            body(a, fa, ca)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        g.replay()
+        body(b, fb, cb)
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state) and torch.equal(fa, fb) and torch.equal(a.counts, b.counts)
+    assert a.status() == 0 and a.stats() == b.stats()
