@@ -38,6 +38,7 @@ struct AutoArgs {
   int32_t* ids;             // out: canonical action id, -1 = not a rule agent's turn / frozen table
   int64_t* stats;           // optional: [T][2] {combinations, search nodes}
   int32_t* status;
+  uint32_t* ticket;         // optional (k_auto2): two zeroed words of the handle's scratch -- tables are handed out one by one
   double rp[24];            // round_penalty by min_oppo_cards (rule_based_model.py:57), computed on the host
 };
 

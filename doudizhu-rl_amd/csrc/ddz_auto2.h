@@ -23,7 +23,13 @@ constexpr int A2_WPB = 8;       // waves per block (17 KB of LDS per wave + the 
 constexpr int A2_TB = A2_WPB * 64;
 constexpr int A2_CAP = 96;      // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
 constexpr int A2_KEYLEVELS = 7; // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
-constexpr int A2_PASSES = 6;    // expansion passes at most
+#ifndef A2_PASSES_N
+#define A2_PASSES_N 6
+#endif
+#ifndef A2_TARGET_N
+#define A2_TARGET_N 64
+#endif
+constexpr int A2_PASSES = A2_PASSES_N;  // expansion passes at most
 constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
 #ifndef A2_SCAN_ROUNDS
@@ -100,6 +106,41 @@ __device__ __forceinline__ int a2_code_digit(int code) { return code < 512 ? cod
 __device__ __forceinline__ int a2_single_v2(int r) { return 2 * (r - 7); }
 __device__ __forceinline__ int a2_pair_v2(int r) { return r - 7 > 0 ? 3 * (r - 7) : 2 * (r - 7); }
 
+// Branch and bound (exact): can a node with `nact` actions worth sum2 on its path, cheapest eligible move cvmin and cards
+// A + B still to cover reach a score >= thr?  An upper bound of rule_based_model.py:60-86 over every completion:
+//   * the values still to come (x 2) sum to at most U2 = floor(sum over the cards of the best value per card any action
+//     of the action space pays for that rank): 4.5 (a bomb) below K, the single's own value from K up (fixture G7);
+//   * at least Lb more actions follow, Lb = ceil(cards / largest candidate of this decision whose lowest rank is not below
+//     the lowest rank left), counted up to 4;
+//   * no action still to come is worth less than the cheapest action whose lowest rank is the lowest rank left.
+// Every operation below is monotone in these three, so the f64 result bounds the f64 score of every completion; a node
+// is skipped only when that bound is STRICTLY below a score some finished combination has reached: neither the maximum
+// nor a tie for it is lost, whatever the order of the search.
+__device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t B, int sum2, int nact, int cvmin,
+                                            uint64_t sm0, uint64_t sm1, double thr) {
+  if (nact == 0) return false;  // the root: the one action that is the whole hand scores +inf (rule_based_model.py:78-81)
+  const uint64_t R = A + B;  // (disjoint ranks)
+  const int nR = nib_sum(R), lo = a2_lowrank(R);
+  const uint32_t hw = (uint32_t)(R >> 40);  // ranks 10..14: K A 2 BJ CJ
+  const int U4 = 9 * nR + 3 * (int)(hw & 15) + 7 * (int)((hw >> 4) & 15) + 11 * (int)((hw >> 8) & 15) +
+                 15 * (int)((hw >> 12) & 15) + 19 * (int)((hw >> 16) & 15);
+  const uint64_t lom = 0ull - (uint64_t)(lo < 8);
+  const int sh = 8 * (lo & 7);
+  int M = (int)((((sm0 & lom) | (sm1 & ~lom)) >> sh) & 0xFF);
+  if (M < 2) M = 2;
+  const int Lb = 1 + (nR > M ? 1 : 0) + (nR > 2 * M ? 1 : 0) + (nR > 3 * M ? 1 : 0);
+  const int L = nact + Lb + (q.follow ? 1 : 0);
+  const int small_num = (L - 1) - (L >= 14 ? 1 : 0);
+  const double total = __dsub_rn((double)(sum2 + (U4 >> 1)) * 0.5, __dmul_rn((double)small_num, q.rp));
+  // cheapest action (x 2) by lowest rank: -14 -12 -10 -8 -6 -4 -2 0 | 2 3 4 8 10 12 14 (non-decreasing)
+  constexpr uint64_t VM0 = 0x00FEFCFAF8F6F4F2ull, VM1 = 0x7F0E0C0A08040302ull;
+  const int m2 = (int)(int8_t)((((VM0 & lom) | (VM1 & ~lom)) >> sh) & 0xFF);
+  const int cm = (cvmin == AUTO_NONE || m2 < cvmin) ? m2 : cvmin;
+  double ub = __dadd_rn(__dsub_rn(total, (double)cm * 0.5), q.rp);
+  if (q.follow && q.pass_ok && total > ub) ub = total;
+  return ub < thr;
+}
+
 template <bool STATE>
 __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
@@ -114,7 +155,20 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   uint16_t* svl = (uint16_t*)W.ci;               // staging views of ci: value | len << 8 ...
   uint16_t* sid = (uint16_t*)W.ci + STAGE_CAP;    // ... and the canonical ids
   constexpr uint64_t NIBM = 0x0FFFFFFFFFFFFFFFull;
-  for (int64_t t = wave0; t < a.T; t += nwaves) {
+  // tables are handed out one by one (a decision costs between 10^4 and 10^6 cycles: a fixed share per wave would end the
+  // launch with its unluckiest wave): ticket[0] = next table, ticket[1] = waves that are done; the last one re-arms both
+  int64_t tstatic = wave0;
+  for (;;) {
+    int64_t t;
+    if (a.ticket) {
+      uint32_t tk = 0;
+      if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+      t = (int64_t)rfl(tk);
+    } else {
+      t = tstatic;
+      tstatic += nwaves;
+    }
+    if (t >= a.T) break;
     // ---- the query: hand, combo to beat, cards left, acting role (as k_auto)
     uint64_t hand;
     uint32_t linfo;
@@ -248,6 +302,73 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       else bsw2 |= v << (9 * (r - 14));
     }
 
+    // ---- 1b. branch and bound (off when the caller wants the exact node / combination counts of the full enumeration)
+    const bool PRUNE = a.stats == nullptr;
+    uint64_t sm0 = 0, sm1 = 0;  // per lowest rank r: the largest candidate whose lowest rank is >= r (bytes)
+    double thr = -__builtin_inf();  // a score some finished combination reaches
+    if (PRUNE) {
+      int mx = 0;  // lane r: the largest candidate of bucket r ...
+      {
+        const int lo_ = lane < 15 ? start_lane : 0, hi_ = lane < 15 ? start_lane + cnt_lane : 0;
+        for (int pp = lo_; pp < hi_; ++pp) {
+          const int c_ = nib_sum(W.cn[pp]);
+          mx = c_ > mx ? c_ : mx;
+        }
+      }
+#pragma unroll
+      for (int r = 14; r >= 0; --r) {  // ... and of every bucket from r up
+        const int v = (int)rl((uint32_t)mx, r);
+        static_assert(STAGE_CAP <= 1023, "positions fit the 10 low bits of the greedy key");
+        const int prev = r == 14 ? 0 : (int)((r + 1 < 8 ? sm0 >> (8 * (r + 1)) : sm1 >> (8 * (r + 1 - 8))) & 0xFF);
+        const uint64_t m_ = (uint64_t)(v > prev ? v : prev);
+        if (r < 8) sm0 |= m_ << (8 * r); else sm1 |= m_ << (8 * (r - 8));
+      }
+      // a first finished combination: always the largest candidate that fits (few actions = a high score)
+      uint64_t gA = hand, gB = 0;
+      int gs = 0, gn = 0, gcv = AUTO_NONE, gid = 0, gfrom = A2_NOFROM;
+      bool stuck = false;
+      for (int step = 0; step < 24 && (gA | gB) != 0 && !stuck; ++step) {
+        const int pr = a2_pend_rank(gA, gB);
+        int v2, id;
+        bool el;
+        if (pr >= 0) {
+          if (a2_pair_option(hand, gB, pr)) { gB -= 2ull << (4 * pr); v2 = a2_pair_v2(pr); el = (q.epair >> pr) & 1u; id = 16 + pr; }
+          else { gB -= 1ull << (4 * pr); v2 = a2_single_v2(pr); el = (q.esingle >> pr) & 1u; id = 1 + pr; }
+        } else {
+          const int ul = a2_lowrank(gA);
+          const int lo_ = gfrom != A2_NOFROM ? gfrom : a2_bs(bsw0, bsw1, bsw2, ul), hi_ = a2_bs(bsw0, bsw1, bsw2, ul + 1);
+          int bk = -1;  // (cards << 10) | (1023 - position): the largest, on ties the first
+          for (int pp = lo_ + lane; pp < hi_; pp += 64) {
+            const uint64_t nb = W.cn[pp];
+            const int k_ = (nib_sum(nb) << 10) | (1023 - pp);
+            if (a2_fits(nb, gA) && k_ > bk) bk = k_;
+          }
+#pragma unroll
+          for (int sft = 32; sft >= 1; sft >>= 1) {
+            const int o_ = __shfl_xor(bk, sft);
+            bk = o_ > bk ? o_ : bk;
+          }
+          bk = (int)rfl((uint32_t)bk);
+          if (bk < 0) { stuck = true; break; }  // (<= 10 cards: the row index may not decrease within a rank)
+          const int ps = 1023 - (bk & 1023);
+          const uint64_t nb = W.cn[ps];
+          const uint32_t ci = W.ci[ps];
+          uint64_t A2, B2;
+          a2_child(q, gA, gB, nb, A2, B2);
+          gfrom = (!q.nosplit && a2_lowrank(A2) == ul) ? ps : A2_NOFROM;
+          gA = A2; gB = B2;
+          v2 = (int)(int8_t)((ci >> 14) & 0xFF); el = (ci >> 22) & 1u; id = (int)(ci & 0x3FFF);
+        }
+        gs += v2; gn += 1;
+        if (el && (gcv == AUTO_NONE || v2 < gcv)) { gcv = v2; gid = id; }
+      }
+      if (!stuck && (gA | gB) == 0) {
+        AutoBest gb{-__builtin_inf(), -1};
+        auto_leaf(gb, gs, gcv, gid, gn, q.follow, q.pass_ok, q.rp);
+        if (gb.move >= 0) thr = gb.value;
+      }
+    }
+
 #ifdef DDZ_STAMP
     tq[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -263,8 +384,13 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     // enough subtrees to feed 64 lanes; the heavy trees (many candidates) get the whole list for balance
-    const int target = 64;
-    for (int pass = 0; pass < A2_PASSES && nitems < target; ++pass) {
+    const int target = A2_TARGET_N;
+#ifdef A2_ADAPT_N
+    const int npass = n <= A2_ADAPT_N ? A2_ADAPT_P : A2_PASSES;
+#else
+    const int npass = A2_PASSES;
+#endif
+    for (int pass = 0; pass < npass && nitems < target; ++pass) {
       // (a) children count and cards left of every item; extra slots wanted per cards-left class
       if (lane < 24) W.hist[lane] = 0;
       __builtin_amdgcn_wave_barrier();
@@ -415,6 +541,15 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
 #else
 #define A2T(k) do { } while (0)
 #endif
+      if (PRUNE && (trip & 3) == 0) {  // the best score any lane has reached so far
+        double bvw = best.move >= 0 ? best.value : -__builtin_inf();
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+          const double o_ = __shfl_xor(bvw, sft);
+          bvw = o_ > bvw ? o_ : bvw;
+        }
+        thr = bvw > thr ? bvw : thr;
+      }
       bool want_score = false, want_open = false, want_back = false;
       int open_from = A2_NOFROM;
       uint64_t idle = __ballot(!act);
@@ -486,6 +621,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         d = 0; more = 0; dead = 0; pendopen = 0;
         A0 = A; B0 = B; sum0 = sum2; n0 = nact;
         if ((A | B) == 0) { want_score = true; }
+        else if (PRUNE && a2_hopeless(q, A, B, sum2, nact, cvmin, sm0, sm1, thr)) { }  // nothing in this subtree can matter
         else { act = true; want_open = true; open_from = (int)((I >> 14) & 1023); }
       }
       if (act && !want_open) {  // one step: the next child of this node, or back to the parent
@@ -542,6 +678,15 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           desc = true;
         } else {
           want_back = true;
+        }
+        if (PRUNE && desc && (A2 | B2) != 0) {
+          const int cvc = (el && (cvmin == AUTO_NONE || v2 < cvmin)) ? v2 : cvmin;
+          if (a2_hopeless(q, A2, B2, sum2 + v2, nact + 1, cvc, sm0, sm1, thr)) {
+            // as if the child had been explored: the cursor moves behind it, the lane stays at this node
+            desc = false;
+            more &= ~(1u << d); pendopen &= ~(1u << d);  // the lane is AT level d again, not below it
+            if (opt == 3) p += 1; else opt += 1;
+          }
         }
         if (desc) {
           W.stack[d][lane] = (uint32_t)code | ((uint32_t)(cvmin & 0xFF) << 10) | ((uint32_t)idmin << 18);
@@ -642,5 +787,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     }
 #endif
     __builtin_amdgcn_wave_barrier();
+  }
+  if (a.ticket && lane == 0 && atomicAdd(a.ticket + 1, 1u) == (uint32_t)(nwaves - 1)) {
+    atomicExch(a.ticket, 0u);
+    atomicExch(a.ticket + 1, 0u);
   }
 }

@@ -2646,6 +2646,7 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
   a.status = e->sc.status;
+  a.ticket = (uint32_t*)(e->sc.status + 8);  // bytes 32..39 of the status block (zero since ddz_create; the kernel re-arms them)
   fill_round_penalty(a);
   return launch_auto<true>(e->device, a, (hipStream_t)stream);
 }

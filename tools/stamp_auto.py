@@ -24,14 +24,15 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 env = pkg.BatchedEnv(T, seed=0)
 env.reset()
 env.legal_slab()
-for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):   # mid-game states of rule farmers against a random lord
     env.step_auto(0b101, slab=True)
+ROLES = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0b111
 buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
 assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-ids = env.auto_choose(0b101)
+ids = env.auto_choose(ROLES)
 e1.record()
 torch.cuda.synchronize()
 assert raw.ddz_debug_set_stamps(None) == 0
