@@ -159,6 +159,8 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   // launch with its unluckiest wave): ticket[0] = next table, ticket[1] = waves that are done; the last one re-arms both
   int64_t tstatic = wave0;
   for (;;) {
+    // (taking the next ticket early, to fetch its state rows while this table is decided, was slower: a wave inside a
+    // 10^6-cycle decision then holds its next table hostage)
     int64_t t;
     if (a.ticket) {
       uint32_t tk = 0;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     for (int u = 0; u < PER; ++u) {
       const int j = u * 64 + lane;
       e_lr[u] = 16; e_nib[u] = 0; e_ci[u] = 0;
-      if (j < n) {
+      if (u * 64 < n && j < n) {  // (the first test is wave-uniform: whole rounds without candidates are skipped)
         const uint64_t e = W.cn[j];
         const uint64_t nib = e & NIBM;
         const int cat = (int)(e >> 60), vl = svl[j], val = vl & 0xFF, len = vl >> 8;
@@ -385,12 +387,51 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     __builtin_amdgcn_wave_barrier();
     // enough subtrees to feed 64 lanes; the heavy trees (many candidates) get the whole list for balance
     const int target = A2_TARGET_N;
+    int pass0 = 0;
+    {  // the first pass has ONE item, the root, and every candidate of its bucket fits: one lane per child
+      const int ul = a2_lowrank(hand);
+      const int lo = a2_bs(bsw0, bsw1, bsw2, ul), hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
+      if (hi - lo >= 1 && hi - lo <= A2_CAP && A2_PASSES > 0) {
+        int wb = 0;
+        for (int p0 = lo; p0 < hi; p0 += 64) {
+          const int pp = p0 + lane;
+          bool keep = false;
+          uint64_t A2 = 0, B2 = 0;
+          uint32_t ci = 0;
+          int v2 = 0;
+          bool el = false;
+          if (pp < hi) {
+            const uint64_t nib = W.cn[pp];
+            ci = W.ci[pp];
+            a2_child(q, hand, 0ull, nib, A2, B2);
+            v2 = (int)(int8_t)((ci >> 14) & 0xFF);
+            el = (ci >> 22) & 1u;
+            keep = !(PRUNE && (A2 | B2) != 0 && a2_hopeless(q, A2, B2, v2, 1, el ? v2 : AUTO_NONE, sm0, sm1, thr));
+          }
+          const uint64_t km = __ballot(keep);
+          if (keep) {
+            const int w = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            const bool same = !q.nosplit && a2_lowrank(A2) == ul;
+            W.itA[1][w] = A2; W.itB[1][w] = B2;
+            W.itM[1][w] = (uint32_t)((v2 + 512) & 1023) | ((uint32_t)((el ? v2 : AUTO_NONE) & 0xFF) << 10) | (1u << 18);
+            W.itI[1][w] = (uint32_t)(el ? (int)(ci & 0x3FFF) : 0) | ((uint32_t)(same ? pp : A2_NOFROM) << 14);
+            W.itK[1][w] = a2_keydigit(0, pp + 1);
+            ++nodes_l;
+          }
+          wb += __popcll(km);
+        }
+        nitems = wb;
+        cur = 1;
+        pass0 = 1;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
 #ifdef A2_ADAPT_N
     const int npass = n <= A2_ADAPT_N ? A2_ADAPT_P : A2_PASSES;
 #else
     const int npass = A2_PASSES;
 #endif
-    for (int pass = 0; pass < npass && nitems < target; ++pass) {
+    for (int pass = pass0; pass < npass && nitems < target; ++pass) {
       // (a) children count and cards left of every item; extra slots wanted per cards-left class
       if (lane < 24) W.hist[lane] = 0;
       __builtin_amdgcn_wave_barrier();
@@ -421,12 +462,24 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       // (b) classes above tau expand entirely, class tau as far as the budget goes (a prefix, in item order)
       const int budget = A2_CAP - nitems;
       int tau = 21, used = 0;
-      for (int c = 20; c >= 1; --c) {
-        const int h = W.hist[c];
-        if (used + h > budget) { tau = c; break; }
-        used += h;
-        tau = c;
-        if (c == 1) tau = 0;  // everything fits
+      {
+        // lane c holds hist[c]; suffix sums over c = 20 .. 1; tau = the first class (from 20 down) whose suffix sum
+        // exceeds the budget (0: everything fits), used = the sum of the classes above it
+        const int hc = (lane >= 1 && lane <= 20) ? W.hist[lane] : 0;
+        int suf = hc;  // inclusive suffix sum: sum of hist[lane .. 20]
+#pragma unroll
+        for (int d_ = 1; d_ < 32; d_ <<= 1) {
+          const int o_ = __shfl_down(suf, d_);
+          if (lane + d_ <= 20) suf += o_;
+        }
+        const uint32_t over = (uint32_t)__ballot(lane >= 1 && lane <= 20 && suf > budget);
+        if (over) {
+          tau = 31 - __builtin_clz(over);
+          used = (int)rl((uint32_t)suf, tau) - (int)rl((uint32_t)hc, tau);
+        } else {
+          tau = 0;
+          used = (int)rl((uint32_t)suf, 1);
+        }
       }
       int mleft = budget - used;  // for the marginal class tau (when tau >= 1 and it did not fit entirely)
       const bool marginal_partial = tau >= 1 && used + W.hist[tau] > budget;
