@@ -19,9 +19,25 @@
 // Included by ddz_engine.hip after ddz_auto.h.
 #pragma once
 
-constexpr int A2_WPB = 8;       // waves per block (17 KB of LDS per wave + the shared record table)
+#ifndef A2_WPB_N
+#define A2_WPB_N 8
+#endif
+#ifndef A2_CAP_N
+#define A2_CAP_N 96
+#endif
+#ifndef A2_DEPTH_N
+#define A2_DEPTH_N 20
+#endif
+#ifndef A2_CAND_N
+#define A2_CAND_N STAGE_CAP
+#endif
+#ifndef A2_WPEU_N
+#define A2_WPEU_N 2
+#endif
+constexpr int A2_CAND = A2_CAND_N;  // candidates per table (diagnostic builds shrink it; the product keeps the proven maximum)
+constexpr int A2_WPB = A2_WPB_N;  // waves per block (17 KB of LDS per wave + the shared record table)
 constexpr int A2_TB = A2_WPB * 64;
-constexpr int A2_CAP = 96;      // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
+constexpr int A2_CAP = A2_CAP_N;  // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
 constexpr int A2_KEYLEVELS = 7; // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
 #ifndef A2_PASSES_N
 #define A2_PASSES_N 6
@@ -30,15 +46,15 @@ constexpr int A2_KEYLEVELS = 7; // order keys: 9-bit digits (child position + 1)
 #define A2_TARGET_N 64
 #endif
 constexpr int A2_PASSES = A2_PASSES_N;  // expansion passes at most
-constexpr int A2_DEPTH = 20;    // actions below an item's root (a combination has at most 20 actions)
+constexpr int A2_DEPTH = A2_DEPTH_N;  // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
 #ifndef A2_SCAN_ROUNDS
 #define A2_SCAN_ROUNDS 1          // candidate-scan rounds (of four candidates) per search-loop trip
 #endif
 
 struct Auto2Wave {              // per wave
-  uint64_t cn[STAGE_CAP];       // candidates: nibble-packed counts (during staging: nib | category << 60, unsorted)
-  uint32_t ci[STAGE_CAP];       // id | (value x 2 & 0xFF) << 14 | fine_mask << 22   (during staging: two u16 arrays)
+  uint64_t cn[A2_CAND];         // candidates: nibble-packed counts (during staging: nib | category << 60, unsorted)
+  uint32_t ci[A2_CAND];         // id | (value x 2 & 0xFF) << 14 | fine_mask << 22   (during staging: two u16 arrays)
   uint64_t itA[2][A2_CAP];      // frontier items (double buffer): remaining hand / untouched ranks
   uint64_t itB[2][A2_CAP];      //   pending surplus of the touched ranks (> 10 cards)
   uint32_t itM[2][A2_CAP];      //   (sum2 + 512) | (cvmin & 0xFF) << 10 | actions so far << 18
@@ -142,7 +158,7 @@ __device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t
 }
 
 template <bool STATE>
-__global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
+__global__ __launch_bounds__(A2_TB, A2_WPEU_N) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
   __shared__ Auto2Wave s_w[A2_WPB];
   const int lane = threadIdx.x & 63;
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __syncthreads();
   Auto2Wave& W = s_w[wv];
   uint16_t* svl = (uint16_t*)W.ci;               // staging views of ci: value | len << 8 ...
-  uint16_t* sid = (uint16_t*)W.ci + STAGE_CAP;    // ... and the canonical ids
+  uint16_t* sid = (uint16_t*)W.ci + A2_CAND;      // ... and the canonical ids
   constexpr uint64_t NIBM = 0x0FFFFFFFFFFFFFFFull;
   // tables are handed out one by one (a decision costs between 10^4 and 10^6 cycles: a fixed share per wave would end the
   // launch with its unluckiest wave): ticket[0] = next table, ticket[1] = waves that are done; the last one re-arms both
@@ -239,12 +255,12 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       n = plan_scan<EM_STAGE, true>(hand, mk_info(EMPTY, 0, 1), hot, lane, o, pk);
     }
     __builtin_amdgcn_wave_barrier();
-    if (n > STAGE_CAP) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
+    if (n > A2_CAND) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
       if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = -1; }
       continue;
     }
     // per candidate (lane holds entries lane, lane + 64, ...: at most 8): value x 2, fine_mask, lowest rank
-    constexpr int PER = (STAGE_CAP + 63) / 64;
+    constexpr int PER = (A2_CAND + 63) / 64;
     uint64_t e_nib[PER];
     uint32_t e_ci[PER];
     int e_lr[PER];
