@@ -66,14 +66,16 @@ env.legal_slab()
 dec = nodes = 0
 st = torch.zeros((T, 2), dtype=torch.int64, device="cuda")
 for it in range(KB):
-    ids = env.auto_choose(0b111, stats=st)
+    ids = env.auto_choose(0b111, stats=st)     # node counts wanted: the full enumeration
+    idb = env.auto_choose(0b111)               # the product path: exact branch and bound
     want = np.concatenate(ref.map(lambda i: ref.parts[i].auto_choose(0b111)))
     assert np.array_equal(ids.cpu().numpy(), want), it
+    assert np.array_equal(idb.cpu().numpy(), want), ("branch and bound", it)
     dec += int((want >= 0).sum()); nodes += int(st[:, 1].sum())
     env.step_slab(ids, pkg.STEP_IDS, auto_reset=True)
     ref.map(lambda i: (ref.parts[i].legal(), ref.parts[i].step(oracle.STEP_IDS, want[cuts[i]:cuts[i + 1]], auto_reset=True)))
     assert np.array_equal(env.state.cpu().numpy(), ref.state()), it
 s = env.stats()
 print(f"B. rule agents on all seats: {T} tables x {KB} iterations = {dec / 1e6:.2f} M decisions ({nodes / 1e9:.2f} G search nodes), "
-      f"ids and states identical every iteration, episodes {s['episodes']}, status {env.status()}, {time.perf_counter() - t0:.0f} s", flush=True)
+      f"ids (full enumeration AND branch and bound) and states identical every iteration, episodes {s['episodes']}, status {env.status()}, {time.perf_counter() - t0:.0f} s", flush=True)
 print("soak ok")
