@@ -170,7 +170,8 @@ class BatchedEnv:
     def auto_choose(self, auto_roles=0b101, out=None, stats=None):
         """The rule agent's move (RuleBasedModel.choose, rule_based/utils/rule_based_model.py:43-101) for every table
         whose actor's role bit is set in auto_roles (bit 0 up, 1 lord, 2 down; default: both farmers): int32[T]
-        canonical action ids, -1 for the other tables.  stats: optional int64 [T,2] {combinations, search nodes}."""
+        canonical action ids, -1 for the other tables.  stats: optional int64 [T,2] {combinations, search nodes} of the full
+        enumeration; without it the kernel runs an exact branch and bound (same ids, ~3x faster)."""
         if out is None:
             out = torch.empty(self.T, dtype=torch.int32, device=self.device)
         if stats is not None and (stats.dtype != torch.int64 or stats.numel() != 2 * self.T or not stats.is_contiguous()):

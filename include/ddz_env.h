@@ -252,7 +252,9 @@ int ddz_pack_trajectory(int device_id, const uint8_t* traj, int64_t n_records, u
  *   ddz_auto_choose: the same for n independent queries (server/core.py:80-87 calls choose() on a payload):
  *     hands / lasts int8[n][16] (byte 15 ignored, `last` all-zero = lead), info u8[n][4] = cards left of role 0, 1, 2
  *     (envi.py:23 `left`) and the acting role; an invalid query (no combo, role > 2, more than 20 cards) yields -1.
- *   stats (may be NULL): int64[n][2] = {combinations scored, search nodes} per table / query.                  */
+ *   stats (may be NULL): int64[n][2] = {combinations scored, search nodes} of the FULL enumeration per table / query.
+ *     With stats == NULL the search is an exact branch and bound (subtrees whose score bound is strictly
+ *     below a score already reached are skipped): the same ids from about a tenth of the nodes, 3x faster.          */
 int ddz_auto_choose_state(ddz_env_t* env, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
 int ddz_auto_choose(int device_id, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n,
                     int32_t* ids, int64_t* stats, void* stream);
