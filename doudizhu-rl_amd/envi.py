@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import config as conf
-from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE, STEP_IDS,
+from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, STEP_CHOICE, STEP_IDS, STEP_ROWS,
                      rows_to_onehot, state_prob)
 
 
@@ -28,6 +28,8 @@ class Env:
         # `if seed:` in the reference (envi.py:18-21): seed 0 / None -> unseeded
         self._seed = int(seed) if seed else random.getrandbits(63)
         self._b = BatchedEnv(1, seed=self._seed, device=self.device)
+        self._sel = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._nlegal = None
         self.debug = debug
         self._clear()
 
@@ -56,6 +58,7 @@ class Env:
     def prepare(self):
         """native shuffle + deal + lord selection (game.py:171); deal = spec v2."""
         self._b.reset()
+        self._nlegal = None
         self._sync()
 
     # ---- native getters used by the callers (SURVEY.md 8b) ----
@@ -82,32 +85,46 @@ class Env:
                           device=self.device)[0].reshape(120).cpu().numpy()
 
     # ---- stepping ----
+    def _ply(self):
+        return int(self._meta[4]) | (int(self._meta[5]) << 8)
+
+    def _step(self, sel, mode):
+        """one engine step + ONE device -> host copy (the 176-byte state): done / r are the meta row's, an action that
+        was not in the legal list leaves the table untouched (same ply counter)"""
+        if self._meta[1]:  # a finished table stays as it is (no auto-reset in this view)
+            return 0, True
+        before = self._ply()
+        self._nlegal = None
+        self._b.step(sel, mode, auto_reset=False)
+        self._sync()
+        if self._ply() == before:
+            raise ValueError("illegal action for the current state")
+        r = int(self._meta[3])
+        return (r - 256 if r > 127 else r), bool(self._meta[1])
+
     def _apply(self, idx):
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        done, r, illegal = self._b.step(torch.tensor([idx], dtype=torch.int32), STEP_CHOICE,
-                                        auto_reset=False)
-        if int(illegal.item()):
-            raise ValueError("illegal action for the current state")
-        res = (int(r.item()), bool(done.item()), None)
-        self._sync()
+        self._sel.fill_(int(idx))
+        r, done = self._step(self._sel, STEP_CHOICE)
+        res = (r, done, None)
         if self.debug:
             print('role {} plays {}, left {}'.format(
                 role, self.cards2str(self.arr2cards(self.recent_handout[role].astype(int))), self.left))
         return res
 
-    def _find(self, arr):
-        offsets, rows, _ = self._b.legal()
-        n = int(offsets[1].item())
-        want = torch.as_tensor(np.asarray(arr, dtype=np.int8), device=self.device)
-        hit = (rows[:n, :15] == want).all(dim=1).nonzero()
-        if hit.numel() == 0:
-            raise ValueError("illegal action for the current state")
-        return int(hit[0].item())
-
     def step_manual(self, onehot_cards):
-        """envi.py:63-70: 15x4 thermometer -> (r, done, _); r -1 lord wins / +1 farmers."""
-        return self._apply(self._find(self.onehot2arr(onehot_cards)))
+        """envi.py:63-70: 15x4 thermometer -> (r, done, _); r -1 lord wins / +1 farmers.  The engine checks the cards
+        against the legal list itself (DDZ_STEP_ROWS)."""
+        role = self.get_role_ID() - 1
+        self.old_cards[role] = self.get_curr_handcards()
+        row = np.zeros((1, 16), np.int8)
+        row[0, :15] = np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8)
+        r, done = self._step(torch.from_numpy(row), STEP_ROWS)
+        if self.debug:
+            print('role {} plays {}, left {}'.format(
+                role, self.cards2str(self.arr2cards(self.recent_handout[role].astype(int))), self.left))
+        return r, done, None
 
     def step_auto(self):
         """envi.py:72-77: the rule-based opponent moves -> (cards, r, _).  The native step_auto is absent from the
@@ -115,18 +132,20 @@ class Env:
         (decomposer spec v1)."""
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        ids = self._b.auto_choose(0b111)
-        done, r, illegal = self._b.step(ids, STEP_IDS, auto_reset=False)
-        if int(illegal.item()):
-            raise RuntimeError("the rule agent chose an illegal action")
-        self._sync()
+        r, _ = self._step(self._b.auto_choose(0b111), STEP_IDS)
         cards = self.arr2cards(self.recent_handout[role].astype(int))
-        return cards, int(r.item()), None
+        return cards, r, None
+
+    def _legal(self):
+        """(rows, n) of the current state; the list size crosses to the host once per state"""
+        if self._nlegal is None or not self._b._legal_fresh:
+            offsets, rows, _ = self._b.legal()
+            self._nlegal = int(offsets[1].item())
+        return self._b.rows, self._nlegal
 
     def step_random(self):
         """envi.py:79-85 with Python's global `random` as in the reference."""
-        offsets, _, _ = self._b.legal()
-        return self._apply(random.randrange(int(offsets[1].item())))
+        return self._apply(random.randrange(self._legal()[1]))
 
     # ---- observations ----
     @property
@@ -135,8 +154,7 @@ class Env:
 
     def valid_actions(self, tensor=True):
         """envi.py:98-116: f32 [A,15,4] on the device, or a list of A int[15] arrays."""
-        offsets, rows, _ = self._b.legal()
-        n = int(offsets[1].item())
+        rows, n = self._legal()
         if tensor:
             return rows_to_onehot(rows[:n])
         return [a for a in rows[:n, :15].cpu().numpy().astype(int)]

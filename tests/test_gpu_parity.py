@@ -1020,6 +1020,16 @@ def test_slab_to_csr_equals_legal(pkg):
             assert torch.equal(off, off2) and int(off2[-1].item()) == tot
             assert torch.equal(rows, rows2[:tot]) and torch.equal(ids, ids2[:tot])
         assert env.status() == 0
+    env = pkg.BatchedEnv(900, seed=6, device=torch.device("cuda:0"), want_ids=False)   # no id buffers at all
+    env.reset()
+    env.rollout_random(11)
+    env.legal_slab()
+    off, rows, ids = env.slab_to_csr(rows_per_table=512)
+    assert ids is None
+    off, tot = off.clone(), int(off[-1].item())
+    rows = rows[:tot].clone()
+    off2, rows2, _ = env.legal()
+    assert torch.equal(off, off2) and torch.equal(rows, rows2[:tot]) and env.status() == 0
     env = pkg.BatchedEnv(300, seed=5, device=torch.device("cuda:0"))
     env.reset()
     env.legal_slab()
