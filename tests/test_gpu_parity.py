@@ -1140,3 +1140,42 @@ def test_stepping_calls_are_graph_capturable(pkg):
     torch.cuda.synchronize()
     assert torch.equal(a.state, b.state) and torch.equal(fa, fb) and torch.equal(a.counts, b.counts)
     assert a.status() == 0 and a.stats() == b.stats()
+
+
+@pytest.mark.parametrize("T", [1, 5, 9])
+def test_slab_api_tiny_table_counts(pkg, oracle, T):
+    """fewer tables than a block has waves (T = 1, 5) and one table more than a block (9): the slab loop in every mode
+    and the fused policy step against the oracle / the separate launches."""
+    rng = np.random.default_rng(T)
+    env = pkg.BatchedEnv(T, seed=77, device=_dev())
+    fus = pkg.BatchedEnv(T, seed=77, device=_dev())
+    ref = oracle.OracleEnv(T, seed=77)
+    env.reset(); ref.reset(); fus.reset()
+    counts, rows, ids = env.legal_slab()
+    fus.legal_slab()
+    for it in range(80):
+        roff, rrows, rids = ref.legal()
+        n = np.diff(roff)
+        assert np.array_equal(counts.cpu().numpy(), n)
+        take = np.arange(env.slab_stride)[None, :] < n[:, None]
+        assert np.array_equal(ids.cpu().numpy()[take], rids) and np.array_equal(rows.cpu().numpy()[take], rrows)
+        q = torch.rand((T, env.slab_stride), dtype=torch.float32, device=_dev())
+        choice = fus.select_slab(q).cpu().numpy()                # the greedy index over q: what the fused step will play
+        mode = it % 3
+        if mode == 0:
+            sel, gm, om = choice, pkg.STEP_CHOICE, oracle.STEP_CHOICE
+        elif mode == 1:
+            sel = np.zeros((T, 16), np.int8)
+            sel[:] = rrows[roff[:-1] + choice]
+            gm, om = pkg.STEP_ROWS, oracle.STEP_ROWS
+        else:
+            sel = rids[roff[:-1] + choice].astype(np.int32)
+            gm, om = pkg.STEP_IDS, oracle.STEP_IDS
+        done, r, ill = env.step_slab(torch.from_numpy(sel).to(_dev()), gm, auto_reset=True)
+        rdone, rr, rill, _ = ref.step(om, sel, auto_reset=True)
+        fd, fr, fi, face = fus.policy_step_slab(q, 0.0, face_variant=int(rng.integers(0, 4)))
+        assert np.array_equal(done.cpu().numpy(), rdone) and np.array_equal(r.cpu().numpy(), rr) and not ill.any()
+        assert np.array_equal(env.state_export().cpu().numpy(), ref.state), it
+        assert torch.equal(fus.state, env.state) and torch.equal(fd, done) and torch.equal(fr, r), it
+        assert torch.equal(fus.counts, env.counts)
+    assert env.status() == 0 and fus.status() == 0
