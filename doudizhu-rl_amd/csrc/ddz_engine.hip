@@ -2379,7 +2379,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
-  a.coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);
+  a.coop = e->slab_coop;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)e->nblocks), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
@@ -2414,7 +2414,7 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  a.coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);
+  a.coop = e->slab_coop;
   const dim3 grid((unsigned)e->nblocks), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
