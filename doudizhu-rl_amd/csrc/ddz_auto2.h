@@ -15,38 +15,22 @@
 //   4. every lane keeps (value, item index, move) of its best scored combination; inside an item the strict `>` of
 //      rule_based_model.py keeps the first maximum, across items the SMALLER item index wins a tie: together exactly
 //      "first maximum in depth-first order", the order the combinations are listed in by decomposer spec v1.
-// Tables are assigned to waves round-robin (t = wave, wave + n_waves, ...): heavy tables average out over a wave's share.
+//   5. branch and bound (exact; a2_hopeless below): a greedy descent gives a first finished combination,
+//      subtrees whose score bound is STRICTLY below a score already reached are skipped -- unless the caller asked for the
+//      node / combination counts of the full enumeration.
+// Tables are handed to the waves one by one through a ticket counter in the handle's scratch (a decision costs between
+// 10^4 and 10^6 cycles); the stateless entry point, which has no scratch, assigns them round-robin.
 // Included by ddz_engine.hip after ddz_auto.h.
 #pragma once
 
-#ifndef A2_WPB_N
-#define A2_WPB_N 8
-#endif
-#ifndef A2_CAP_N
-#define A2_CAP_N 96
-#endif
-#ifndef A2_DEPTH_N
-#define A2_DEPTH_N 20
-#endif
-#ifndef A2_CAND_N
-#define A2_CAND_N STAGE_CAP
-#endif
-#ifndef A2_WPEU_N
-#define A2_WPEU_N 2
-#endif
-constexpr int A2_CAND = A2_CAND_N;  // candidates per table (diagnostic builds shrink it; the product keeps the proven maximum)
-constexpr int A2_WPB = A2_WPB_N;  // waves per block (17 KB of LDS per wave + the shared record table)
+constexpr int A2_CAND = STAGE_CAP;  // candidates per table: the proven maximum of a <= 20-card hand
+constexpr int A2_WPB = 8;         // waves per block (17 KB of LDS per wave + the shared record table)
 constexpr int A2_TB = A2_WPB * 64;
-constexpr int A2_CAP = A2_CAP_N;  // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
-constexpr int A2_KEYLEVELS = 7; // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
-#ifndef A2_PASSES_N
-#define A2_PASSES_N 6
-#endif
-#ifndef A2_TARGET_N
-#define A2_TARGET_N 64
-#endif
-constexpr int A2_PASSES = A2_PASSES_N;  // expansion passes at most
-constexpr int A2_DEPTH = A2_DEPTH_N;  // actions below an item's root (a combination has at most 20 actions)
+constexpr int A2_CAP = 96;        // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
+constexpr int A2_KEYLEVELS = 7;   // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
+constexpr int A2_PASSES = 6;      // expansion passes at most
+constexpr int A2_TARGET = 64;     // ... or until the list feeds 64 lanes
+constexpr int A2_DEPTH = 20;      // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
 #ifndef A2_SCAN_ROUNDS
 #define A2_SCAN_ROUNDS 1          // candidate-scan rounds (of four candidates) per search-loop trip
@@ -158,7 +142,7 @@ __device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t
 }
 
 template <bool STATE>
-__global__ __launch_bounds__(A2_TB, A2_WPEU_N) void k_auto2(AutoArgs a) {
+__global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
   __shared__ Auto2Wave s_w[A2_WPB];
   const int lane = threadIdx.x & 63;
@@ -402,7 +386,7 @@ __global__ __launch_bounds__(A2_TB, A2_WPEU_N) void k_auto2(AutoArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     // enough subtrees to feed 64 lanes; the heavy trees (many candidates) get the whole list for balance
-    const int target = A2_TARGET_N;
+    const int target = A2_TARGET;
     int pass0 = 0;
     {  // the first pass has ONE item, the root, and every candidate of its bucket fits: one lane per child
       const int ul = a2_lowrank(hand);
@@ -442,11 +426,7 @@ __global__ __launch_bounds__(A2_TB, A2_WPEU_N) void k_auto2(AutoArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
     }
-#ifdef A2_ADAPT_N
-    const int npass = n <= A2_ADAPT_N ? A2_ADAPT_P : A2_PASSES;
-#else
     const int npass = A2_PASSES;
-#endif
     for (int pass = pass0; pass < npass && nitems < target; ++pass) {
       // (a) children count and cards left of every item; extra slots wanted per cards-left class
       if (lane < 24) W.hist[lane] = 0;
