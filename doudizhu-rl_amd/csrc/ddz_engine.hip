@@ -1264,6 +1264,11 @@ __device__ __attribute__((noinline)) void face_phase(uint4* srow, int ntab, int 
   else face_chunk<6, 0x876510ull>(srow, side, ntab, face + t0 * (6 * 15), lane);
 }
 
+// the same counts (the category byte of a caller's row is ignored)
+__device__ __forceinline__ bool row_eq(uint4 r, uint4 w) {
+  return r.x == w.x && r.y == w.y && r.z == w.z && ((r.w ^ w.w) & 0x00FFFFFFu) == 0;
+}
+
 // Round-2b layout: the decode / selection / apply of a chunk of up to SLAB_CH tables is ONE lane-parallel pass (lane i
 // = table t0 + i) over the chunk's state rows staged in the wave's LDS buffer -- the staging list of the list code,
 // idle in this phase -- instead of one wave-wide pass per table; only the deal of a finished game, the wave-parallel
@@ -1419,24 +1424,32 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
           if (sel_l < 0 || sel_l >= NIDS) need = false;  // no such action: not in any list
           c = row_of_id(need ? sel_l : 0);
         }
-        uint64_t nm = __ballot(need);
-        while (nm) {
-          const int i = __builtin_ctzll(nm);
-          nm &= nm - 1;
-          const uint4 want = make_uint4(rl(c.x, i), rl(c.y, i), rl(c.z, i), rl(c.w, i));
-          const int Ai = (int)rl((uint32_t)A, i);
-          const uint4* lrow = a.rows + (t0 + i) * a.stride;
-          int found = -1;
-          for (int j0 = 0; j0 < Ai && found < 0; j0 += 64) {
-            bool hit = false;
-            if (j0 + lane < Ai) {
-              const uint4 r = lrow[j0 + lane];
-              hit = r.x == want.x && r.y == want.y && r.z == want.z && ((r.w ^ want.w) & 0x00FFFFFFu) == 0;
-            }
-            const uint64_t hb = __ballot(hit);
-            if (hb) found = j0 + __builtin_ctzll(hb);
+        // every table's list is searched by 4 lanes (lane 4g + s looks at rows s, s + 4, ..., two loads in flight per
+        // trip): 16 tables at once instead of one table per wave-wide pass (the arg-max of STEP_Q is laid out the same way)
+        {
+          static_assert(SLAB_CH * 4 == 64, "4 lanes per table of the chunk");
+          const int g = lane >> 2;
+          const uint4 want = make_uint4(__shfl(c.x, g), __shfl(c.y, g), __shfl(c.z, g), __shfl(c.w, g));
+          // (every shuffle with all lanes active: inside a `needg ? __shfl(A, g) : 0` the source lanes of a table that does
+          // not search are switched off and the bpermute returns garbage for the groups that read them)
+          const int needg = __shfl(need ? 1 : 0, g);
+          const int Aof = __shfl(A, g);
+          const int Ag = needg ? Aof : 0;
+          const uint4* lrow = a.rows + (t0 + g) * a.stride;
+          int found = 0x7FFFFFFF;
+          for (int j0 = lane & 3; j0 < Ag && found == 0x7FFFFFFF; j0 += 8) {
+            const uint4 r0 = lrow[j0];
+            const uint4 r1 = j0 + 4 < Ag ? lrow[j0 + 4] : make_uint4(~0u, 0, 0, 0);
+            if (j0 + 4 < Ag && row_eq(r1, want)) found = j0 + 4;
+            if (row_eq(r0, want)) found = j0;
           }
-          if (lane == i) idx = found;
+#pragma unroll
+          for (int dd = 1; dd < 4; dd <<= 1) {
+            const int o_ = __shfl_xor(found, dd);
+            found = o_ < found ? o_ : found;
+          }
+          const int mine = __shfl(found, (lane & (SLAB_CH - 1)) * 4);
+          if (need) idx = mine == 0x7FFFFFFF ? -1 : mine;
         }
       }
       if (idx >= 0) c = a.rows[t * a.stride + idx];  // the listed row carries the category byte
