@@ -48,7 +48,8 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
     for k, nm in enumerate(names):
         per = s[:, k] / (ntab if k >= 2 else 1)
         print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}  max {per.max():8.0f}")
-    print(f"  total per wave mean {s[:, :5].sum(1).mean():8.0f} cycles")
+    tw = s[:, :5].sum(1)
+    print(f"  total per wave mean {tw.mean():8.0f} cycles  p50 {np.percentile(tw, 50):8.0f}  p99 {np.percentile(tw, 99):8.0f}  max {tw.max():8.0f}")
     # the fused policy iteration (ddz_policy_step_slab): arg-max in the prologue, `face` between apply and lists
     q = torch.rand((T, env.slab_stride), dtype=torch.float32, device="cuda")
     face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device="cuda")
