@@ -59,6 +59,8 @@ SYMBOLS = {
     "ddz_auto_choose": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "ddz_debug_cards_value": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "ddz_debug_auto_choose_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_debug_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
@@ -68,12 +70,24 @@ class DdzError(RuntimeError):
     pass
 
 
+_override = None
+
+
+def use_library(path):
+    """Diagnostics (tools/): load this build of the default library instead of csrc/libddz_hip.so -- an explicit call
+    before the first use, never an environment variable."""
+    global _override
+    if False in _libs:
+        raise DdzError("use_library() must be called before the library is first used")
+    _override = path
+
+
 def lib(jk=False):
     """Load libddz_hip.so (jk=True: libddz_hip_jk.so, the rule set with the 24 joker-kicker rows);
     raises (never falls back) when it is absent."""
     jk = bool(jk)
     if jk not in _libs:
-        LIB = _JK_LIB if jk else (os.environ.get("DDZ_HIP_LIB") or _DEFAULT_LIB)  # override: tools/variants.py
+        LIB = _JK_LIB if jk else (_override or _DEFAULT_LIB)
         if not os.path.exists(LIB):
             raise DdzError(
                 f"{LIB} is missing: build it with `python __graft_entry__.py build` "

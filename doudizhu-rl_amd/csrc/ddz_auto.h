@@ -35,10 +35,10 @@ struct AutoArgs {
   int64_t T;
   int tpw;
   int auto_roles;           // STATE form: bit r = role r is played by the rule agent
-  int32_t* ids;             // out: canonical action id, -1 = not a rule agent's turn / frozen table
+  int32_t* ids;             // out: canonical action id, -1 = not a rule agent's turn / frozen table, DDZ_AUTO_INVALID = bad query
   int64_t* stats;           // optional: [T][2] {combinations, search nodes}
   int32_t* status;
-  uint32_t* ticket;         // optional (k_auto2): two zeroed words of the handle's scratch -- tables are handed out one by one
+  uint32_t* ticket;         // k_auto2: this launch's own zeroed ticket word -- tables are handed out one by one
   double rp[24];            // round_penalty by min_oppo_cards (rule_based_model.py:57), computed on the host
 };
 
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
     uint64_t hand;
     uint32_t linfo;
     int role, left0, left1, left2;
-    bool active;
+    bool active, invalid = false;
     if (STATE) {
       uint4 R = make_uint4(0, 0, 0, 0);
       if (lane < DDZ_NFIELDS) R = ((const uint4*)(a.state + t * STATE_ROW_BYTES))[lane];
@@ -167,16 +167,18 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
       active = true;
       if (linfo == INFO_INVALID || ge_mask(hand, 5) || (hand >> 60) || role > 2) {  // no combo of the action space
         if (lane == 0 && a.status) atomicOr(a.status, 4);
-        active = false;
+        active = false; invalid = true;
       }
     }
     if (active && nib_sum(hand) > 20) {  // no player ever holds more than 20 cards: the search is sized for that
       if (lane == 0 && a.status) atomicOr(a.status, 4);
-      active = false;
+      active = false; invalid = true;
     }
     if (!active || hand == 0) {
       if (lane == 0) {
-        a.ids[t] = -1;
+        // -1 = not a rule agent's turn (DDZ_STEP_IDS: engine RNG); an invalid query is NOT that: DDZ_AUTO_INVALID is no
+        // action id, so DDZ_STEP_IDS flags the table illegal instead of silently playing a random move
+        a.ids[t] = invalid ? DDZ_AUTO_INVALID : -1;
         if (a.stats) { a.stats[2 * t] = 0; a.stats[2 * t + 1] = 0; }
       }
       continue;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     if (n > STAGE_CAP) {  // cannot happen for a <= 20-card hand
-      if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = -1; }
+      if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = DDZ_AUTO_INVALID; }
       continue;
     }
     // ---- 2. per candidate: cards_value x 2, fine_mask bit, lowest rank; counting sort by lowest rank

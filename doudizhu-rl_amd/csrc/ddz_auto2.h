@@ -18,8 +18,8 @@
 //   5. branch and bound (exact; a2_hopeless below): a greedy descent gives a first finished combination,
 //      subtrees whose score bound is STRICTLY below a score already reached are skipped -- unless the caller asked for the
 //      node / combination counts of the full enumeration.
-// Tables are handed to the waves one by one through a ticket counter in the handle's scratch (a decision costs between
-// 10^4 and 10^6 cycles); the stateless entry point, which has no scratch, assigns them round-robin.
+// Tables are handed to the waves one by one through a per-launch ticket counter (a decision costs between 10^4 and 10^6
+// cycles), for the handle's entry point and the stateless one alike.
 // Included by ddz_engine.hip after ddz_auto.h.
 #pragma once
 
@@ -32,6 +32,8 @@ constexpr int A2_PASSES = 6;      // expansion passes at most
 constexpr int A2_TARGET = 64;     // ... or until the list feeds 64 lanes
 constexpr int A2_DEPTH = 20;      // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
+constexpr int A2_TICKET_SLOTS = 1024;  // ring of per-launch ticket words (ddz_engine.hip launch_auto)
+__device__ uint32_t g_tickets[A2_TICKET_SLOTS];
 #ifndef A2_SCAN_ROUNDS
 #define A2_SCAN_ROUNDS 1          // candidate-scan rounds (of four candidates) per search-loop trip
 #endif
@@ -147,8 +149,6 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ Auto2Wave s_w[A2_WPB];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
-  const int64_t wave0 = (int64_t)blockIdx.x * A2_WPB + wv;
-  const int64_t nwaves = (int64_t)gridDim.x * A2_WPB;
   hot_fill<A2_TB>(hot);
   __syncthreads();
   Auto2Wave& W = s_w[wv];
@@ -156,26 +156,21 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   uint16_t* sid = (uint16_t*)W.ci + A2_CAND;      // ... and the canonical ids
   constexpr uint64_t NIBM = 0x0FFFFFFFFFFFFFFFull;
   // tables are handed out one by one (a decision costs between 10^4 and 10^6 cycles: a fixed share per wave would end the
-  // launch with its unluckiest wave): ticket[0] = next table, ticket[1] = waves that are done; the last one re-arms both
-  int64_t tstatic = wave0;
+  // launch with its unluckiest wave): *ticket = next table.  The word belongs to THIS launch alone (the host takes it from
+  // a ring of device globals and zeroes it on the launch stream, ddz_engine.hip launch_auto): nothing to re-arm, nothing a
+  // failed or concurrent launch can leave behind.  Every wave leaves when it draws a ticket >= T: the grid always drains.
   for (;;) {
     // (taking the next ticket early, to fetch its state rows while this table is decided, was slower: a wave inside a
     // 10^6-cycle decision then holds its next table hostage)
-    int64_t t;
-    if (a.ticket) {
-      uint32_t tk = 0;
-      if (lane == 0) tk = atomicAdd(a.ticket, 1u);
-      t = (int64_t)rfl(tk);
-    } else {
-      t = tstatic;
-      tstatic += nwaves;
-    }
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+    const int64_t t = (int64_t)rfl(tk);
     if (t >= a.T) break;
     // ---- the query: hand, combo to beat, cards left, acting role (as k_auto)
     uint64_t hand;
     uint32_t linfo;
     int role, left0, left1, left2;
-    bool active;
+    bool active, invalid = false;
     if (STATE) {
       uint4 R = make_uint4(0, 0, 0, 0);
       if (lane < DDZ_NFIELDS) R = ((const uint4*)(a.state + t * STATE_ROW_BYTES))[lane];
@@ -199,16 +194,18 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       active = true;
       if (linfo == INFO_INVALID || ge_mask(hand, 5) || (hand >> 60) || role > 2) {  // no combo of the action space
         if (lane == 0 && a.status) atomicOr(a.status, 4);
-        active = false;
+        active = false; invalid = true;
       }
     }
     if (active && nib_sum(hand) > 20) {  // no player ever holds more than 20 cards: the search is sized for that
       if (lane == 0 && a.status) atomicOr(a.status, 4);
-      active = false;
+      active = false; invalid = true;
     }
     if (!active || hand == 0) {
       if (lane == 0) {
-        a.ids[t] = -1;
+        // -1 = not a rule agent's turn (DDZ_STEP_IDS: engine RNG); an invalid query is NOT that: DDZ_AUTO_INVALID is no
+        // action id, so DDZ_STEP_IDS flags the table illegal instead of silently playing a random move
+        a.ids[t] = invalid ? DDZ_AUTO_INVALID : -1;
         if (a.stats) { a.stats[2 * t] = 0; a.stats[2 * t + 1] = 0; }
       }
       continue;
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     if (n > A2_CAND) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
-      if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = -1; }
+      if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = DDZ_AUTO_INVALID; }
       continue;
     }
     // per candidate (lane holds entries lane, lane + 64, ...: at most 8): value x 2, fine_mask, lowest rank
@@ -836,9 +833,5 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     }
 #endif
     __builtin_amdgcn_wave_barrier();
-  }
-  if (a.ticket && lane == 0 && atomicAdd(a.ticket + 1, 1u) == (uint32_t)(nwaves - 1)) {
-    atomicExch(a.ticket, 0u);
-    atomicExch(a.ticket + 1, 0u);
   }
 }

@@ -120,7 +120,7 @@ constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS stagin
 constexpr int EM_MASK = 4;    // bit `id` of the wave's LDS mask (get_mask, utils.py:45-63)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
-constexpr int STAGE_CAP = DDZ_NATIVE_JOKER_KICKERS ? 512 : 500;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
+constexpr int STAGE_CAP = 500;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
                                  // 500 keeps k_rollout's block at 53 KB of LDS = three blocks per CU
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
@@ -1678,9 +1678,11 @@ __global__ __launch_bounds__(CSR_BT) void k_csr_copy(const int32_t* __restrict__
   int c = t < n ? counts[t] : 0;
   if (c < 0 || c > stride) c = 0;
   const long long off = base + (t < n ? local_off[t] : 0);
-  if (t < n) offsets[t] = (int32_t)off;
+  // offsets are clamped to the capacity: a consumer that indexes rows_out[offsets[t] .. offsets[t+1]) never leaves the
+  // buffer (a truncated list is shorter / empty; status bit 1 says that it happened)
+  if (t < n) offsets[t] = (int32_t)(off < cap ? off : cap);
   if (t == n - 1) {
-    offsets[n] = (int32_t)(off + c);
+    offsets[n] = (int32_t)(off + c < cap ? off + c : cap);
     if (off + c > cap && status) atomicOr(status, 2);
   }
   // every wave copies the lists of its 64 tables flat: output row r of the wave belongs to the last table whose
@@ -2059,18 +2061,12 @@ inline int check_launch() {
   return e == hipSuccess ? DDZ_OK : hip_fail(e);
 }
 
-inline int env_int(const char* name, int lo, int hi, int dflt) {
-  if (const char* s = getenv(name)) {
-    int v = atoi(s);
-    if (v >= lo && v <= hi) return v;
-  }
-  return dflt;
-}
 // tables per wave: one table per wave until the chip is full (256 CUs x 16 waves), then
-// consecutive tables share a wave so that the per-wave CSR prefix stays short
+// consecutive tables share a wave so that the per-wave CSR prefix stays short.  (No environment switches in the
+// library: tests and diagnostics change the geometry of a handle through ddz_debug_set_geometry.)
 inline int pick_tpw(int64_t T) {
   int64_t v = (T + 4095) / 4096;
-  return env_int("DDZ_TPW", 1, 64, (int)(v < 1 ? 1 : v > 32 ? 32 : v));
+  return (int)(v < 1 ? 1 : v > 32 ? 32 : v);
 }
 
 int launch_moves(const Scratch& sc, const int8_t* hands, const int8_t* lasts, int64_t n, int32_t* offsets,
@@ -2100,6 +2096,7 @@ constexpr int MAX_DEVICES = 64;
 // read with acquire / written with release so that a reader never sees a half-built table.
 std::mutex g_table_mutex[MAX_DEVICES];
 std::atomic<bool> g_table_ready[MAX_DEVICES];
+extern uint32_t* g_ticket_base[MAX_DEVICES];
 int build_table_locked(int device);
 int ensure_table(int device) {
   if (device < 0 || device >= MAX_DEVICES) return DDZ_ENODEV;
@@ -2111,7 +2108,12 @@ int ensure_table(int device) {
   return rc;
 }
 int build_table_locked(int device) {
-  (void)device;
+  {
+    void* tk = nullptr;
+    const hipError_t r0 = hipGetSymbolAddress(&tk, HIP_SYMBOL(g_tickets));
+    if (r0 != hipSuccess) return hip_fail(r0);
+    g_ticket_base[device] = (uint32_t*)tk;
+  }
   int32_t* flag = nullptr;
   hipError_t r = hipHostMalloc((void**)&flag, sizeof(int32_t), 0);  // host-pinned status word
   if (r != hipSuccess) return hip_fail(r);
@@ -2240,12 +2242,24 @@ static int auto_blocks(int device, int64_t n) {
   const int64_t cap = device >= 0 && device < MAX_DEVICES ? cus[device] : 256;
   return (int)(want < cap ? want : cap);
 }
+// k_auto2 hands its tables out through a ticket word (next table to take).  Every launch gets its OWN word from a
+// per-device ring of device globals, zeroed on the launch stream right before the kernel: no re-arm protocol, nothing a
+// failed / rejected / concurrent launch (another stream of the same handle, the stateless entry point) can leave behind.
+std::atomic<uint32_t> g_ticket_next[MAX_DEVICES];
+uint32_t* g_ticket_base[MAX_DEVICES];  // device address of g_tickets, resolved once per device (under the table mutex)
+constexpr int AUTO_K_SEQUENTIAL = 1, AUTO_K_LANES = 2;
 template <bool STATE>
-static int launch_auto(int device, const AutoArgs& a, hipStream_t st) {
-  if (env_int("DDZ_AUTO_KERNEL", 1, 2, 2) == 1)
+static int launch_auto(int device, AutoArgs& a, hipStream_t st, int kernel = AUTO_K_LANES) {
+  if (kernel == AUTO_K_SEQUENTIAL) {  // the sequential cross-check kernel (ddz_debug_auto_choose_state only)
     hipLaunchKernelGGL(k_auto<STATE>, dim3((unsigned)((a.T + WPB - 1) / WPB)), dim3(TB), 0, st, a);
-  else
-    hipLaunchKernelGGL(k_auto2<STATE>, dim3((unsigned)auto_blocks(device, a.T)), dim3(A2_TB), 0, st, a);
+    return check_launch();
+  }
+  if (device < 0 || device >= MAX_DEVICES || !g_ticket_base[device]) return DDZ_ENODEV;
+  const uint32_t slot = g_ticket_next[device].fetch_add(1u, std::memory_order_relaxed) % A2_TICKET_SLOTS;
+  a.ticket = g_ticket_base[device] + slot;
+  const hipError_t r = hipMemsetAsync(a.ticket, 0, sizeof(uint32_t), st);
+  if (r != hipSuccess) return hip_fail(r);
+  hipLaunchKernelGGL(k_auto2<STATE>, dim3((unsigned)auto_blocks(device, a.T)), dim3(A2_TB), 0, st, a);
   return check_launch();
 }
 
@@ -2304,7 +2318,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->tpw = pick_tpw(T);
   e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
-  e->slab_coop = e->tpw == 1 && env_int("DDZ_SLAB_COOP", 0, 1, 1);  // (0: diagnostic, tools/)
+  e->slab_coop = e->tpw == 1;
   *out = e;
   return DDZ_OK;
 }
@@ -2659,9 +2673,37 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
   a.status = e->sc.status;
-  a.ticket = (uint32_t*)(e->sc.status + 8);  // bytes 32..39 of the status block (zero since ddz_create; the kernel re-arms them)
   fill_round_penalty(a);
   return launch_auto<true>(e->device, a, (hipStream_t)stream);
+}
+
+// test hook: ddz_auto_choose_state with an explicit kernel -- 1 = k_auto (sequential walk, wave-uniform control, full
+// enumeration: the cross-check), 2 = k_auto2 (the product kernel).  Same ids by construction; tests compare them.
+int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!ids || !al(ids, 4) || !al(stats, 8) || auto_roles < 0 || auto_roles > 7) return DDZ_EINVAL;
+  if (kernel != AUTO_K_SEQUENTIAL && kernel != AUTO_K_LANES) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  AutoArgs a{};
+  a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
+  a.status = e->sc.status;
+  fill_round_penalty(a);
+  return launch_auto<true>(e->device, a, (hipStream_t)stream, kernel);
+}
+
+// test hook: the launch geometry of a handle's table kernels -- tables per wave (1..64, 0 = keep) and whether k_slab runs
+// the one-table-per-wave block-cooperative form (0 / 1, -1 = keep).  Results never depend on either (tests sweep them).
+int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1) return DDZ_EINVAL;
+  if (tables_per_wave > 0) {
+    e->tpw = tables_per_wave;
+    e->nblocks = (e->T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
+    e->counts_valid = false;  // the scan buffers depend on the geometry
+  }
+  e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
+  return DDZ_OK;
 }
 
 int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n, int32_t* ids,

@@ -46,7 +46,7 @@ class BatchedEnv:
     """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
-                 want_ids=True, native_joker_kickers=False):
+                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None):
         # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
         # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
         self.native_joker_kickers = bool(native_joker_kickers)
@@ -71,7 +71,7 @@ class BatchedEnv:
         self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self._stats = torch.zeros(8, dtype=torch.int64, device=d)
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
         # raw pointers of the persistent buffers, converted once (the host side of a call is ~10 us of ctypes work)
         self._pp = {k: _p(getattr(self, k)) for k in ("counts", "rows", "ids", "done", "reward", "illegal", "offsets")}
         h = C.c_void_p()
@@ -79,6 +79,9 @@ class BatchedEnv:
                                   _p(self.state), self.state.numel(), _p(self.scratch),
                                   self.scratch.numel()))
         self._h = h
+        if _debug_tables_per_wave is not None or _debug_slab_coop is not None:  # test hook: results never depend on it
+            check(self.lib.ddz_debug_set_geometry(h, int(_debug_tables_per_wave or 0),
+                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop))))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -110,7 +113,7 @@ class BatchedEnv:
             if mask.numel() != self.T:
                 raise ValueError("mask must have one byte per table")
         check(self.lib.ddz_reset(self._h, _p(mask), _stream(self.device)))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
     def legal(self):
         """CSR legal-move lists of all tables (envi.py:98-116 valid_actions(tensor=False)).
@@ -118,7 +121,7 @@ class BatchedEnv:
         offsets[T] rows are meaningful.  No host sync."""
         check(self.lib.ddz_legal(self._h, _p(self.offsets), _p(self.rows), _p(self.ids), self.cap,
                                  _stream(self.device)))
-        self._legal_fresh, self._slab_fresh = True, False  # legal() packed CSR rows into the row buffer
+        self._legal_fresh, self._slab_fresh, self._csr_fresh = True, False, False  # legal() packed CSR rows into the row buffer
         return self.offsets, self.rows, self.ids
 
     def _need_legal(self):
@@ -149,7 +152,7 @@ class BatchedEnv:
                                 _p(self.offsets), _p(self.rows), int(bool(auto_reset)),
                                 _p(self.done), _p(self.reward), _p(self.illegal), _p(traj),
                                 _stream(self.device)))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
         return self.done, self.reward, self.illegal
 
     def step_onehot(self, actions, auto_reset=True, traj=None):
@@ -167,16 +170,21 @@ class BatchedEnv:
         return self.step(None, STEP_RANDOM, auto_reset, traj)
 
     # ---- rule-based opponent (envi.py:72-77 step_auto) ----
-    def auto_choose(self, auto_roles=0b101, out=None, stats=None):
+    def auto_choose(self, auto_roles=0b101, out=None, stats=None, _debug_kernel=None):
         """The rule agent's move (RuleBasedModel.choose, rule_based/utils/rule_based_model.py:43-101) for every table
         whose actor's role bit is set in auto_roles (bit 0 up, 1 lord, 2 down; default: both farmers): int32[T]
-        canonical action ids, -1 for the other tables.  stats: optional int64 [T,2] {combinations, search nodes} of the full
+        canonical action ids, -1 for the other tables (-2 = DDZ_AUTO_INVALID: a state the agent cannot decide, which
+        DDZ_STEP_IDS flags illegal -- never a silent random move).  stats: optional int64 [T,2] {combinations, search nodes} of the full
         enumeration; without it the kernel runs an exact branch and bound (same ids, ~3x faster)."""
         if out is None:
             out = torch.empty(self.T, dtype=torch.int32, device=self.device)
         if stats is not None and (stats.dtype != torch.int64 or stats.numel() != 2 * self.T or not stats.is_contiguous()):
             raise ValueError("stats must be a contiguous int64 [T,2] tensor")
-        check(self.lib.ddz_auto_choose_state(self._h, int(auto_roles), _p(out), _p(stats), _stream(self.device)))
+        if _debug_kernel is not None:  # test hook: 1 = the sequential cross-check kernel, 2 = the product kernel
+            check(self.lib.ddz_debug_auto_choose_state(self._h, int(_debug_kernel), int(auto_roles), _p(out), _p(stats),
+                                                       _stream(self.device)))
+        else:
+            check(self.lib.ddz_auto_choose_state(self._h, int(auto_roles), _p(out), _p(stats), _stream(self.device)))
         return out
 
     def step_auto(self, auto_roles=0b101, ids=None, auto_reset=True, traj=None, slab=False):
@@ -201,7 +209,8 @@ class BatchedEnv:
     def select(self, q, epsilon=0.0, out=None):
         """greedy / epsilon-greedy choice per table from per-row values q (f32, CSR order of
         the current legal list; dqn.py:50-71).  Returns int32[T] indices for step(STEP_CHOICE)."""
-        self._need_legal()
+        if not self._csr_fresh:   # after slab_to_csr() the offsets already describe the current lists: no ddz_legal
+            self._need_legal()
         q = q.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
         if out is None:
             out = torch.empty(self.T, dtype=torch.int32, device=self.device)
@@ -269,7 +278,7 @@ class BatchedEnv:
             raise ValueError(f"slab lists need row_capacity >= {MAX_LEGAL_PER_TABLE} * n_tables")
         check(self.lib.ddz_legal_slab(self._h, _p(self.counts), _p(self.rows), _p(self.ids), self.slab_stride,
                                       _stream(self.device)))
-        self._legal_fresh = False  # the CSR buffers (offsets) do not describe the row buffer any more
+        self._legal_fresh = self._csr_fresh = False  # the CSR buffers (offsets) do not describe the row buffer any more
         self._slab_fresh = True
         return self.counts, self.slab_rows(), self.slab_ids()
 
@@ -299,7 +308,7 @@ class BatchedEnv:
                                      pp["rows"], pp["ids"], self.slab_stride, 1 if auto_reset else 0,
                                      pp["done"], pp["reward"], pp["illegal"], _p(traj),
                                      _stream(self.device)))
-        self._legal_fresh, self._slab_fresh = False, True  # the buffers hold the lists of the new states
+        self._legal_fresh, self._slab_fresh, self._csr_fresh = False, True, False  # the buffers hold the lists of the new states
         return self.done, self.reward, self.illegal
 
     def policy_step_slab(self, q, epsilon=0.0, face_variant=None, face_out=None, choice_out=None, auto_reset=True,
@@ -330,7 +339,7 @@ class BatchedEnv:
                                             pp["illegal"], _p(traj), _p(choice_out),
                                             int(face_variant) if face_variant is not None else 0, _p(face),
                                             _stream(self.device)))
-        self._legal_fresh, self._slab_fresh = False, True
+        self._legal_fresh, self._slab_fresh, self._csr_fresh = False, True, False
         return self.done, self.reward, self.illegal, face
 
     def slab_to_csr(self, rows_per_table=64):
@@ -347,6 +356,7 @@ class BatchedEnv:
             self._csr_cap = cap
         check(self.lib.ddz_slab_to_csr(self._h, self._pp["counts"], self._pp["rows"], self._pp["ids"], self.slab_stride,
                                        self._pp["offsets"], _p(self.csr_rows), _p(self.csr_ids), cap, _stream(self.device)))
+        self._csr_fresh = True    # select(q_csr) may use self.offsets as they are; the slab lists stay valid for step_slab
         return self.offsets, self.csr_rows, self.csr_ids
 
     def rollout_random(self, n_iters, traj=None):
@@ -361,7 +371,7 @@ class BatchedEnv:
         check(self.lib.ddz_rollout_random(self._h, int(n_iters), _p(self.counts), _p(self.rows),
                                           _p(self.ids), self.slab_stride, _p(self._stats), _p(traj),
                                           _stream(self.device)))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
     def rollout_random_csr(self, n_iters, traj=None):
         """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them); one
@@ -372,7 +382,7 @@ class BatchedEnv:
             raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
         check(self.lib.ddz_rollout_random_csr(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
                                               _p(self.ids), self.cap, _p(traj), _stream(self.device)))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
     def rollout_random_timed(self, n_iters):
         """Same loop between two hipEvents; returns the elapsed ms of the n_iters launches.
@@ -381,7 +391,7 @@ class BatchedEnv:
         check(self.lib.ddz_rollout_random_timed(self._h, int(n_iters), _p(self.counts), _p(self.rows),
                                                 _p(self.ids), self.slab_stride, ms,
                                                 _stream(self.device)))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
         return ms[0]
 
     def stats(self):
@@ -406,7 +416,7 @@ class BatchedEnv:
             raise ValueError("state size mismatch")
         self.state.copy_(state.to(self.device).view(-1))
         check(self.lib.ddz_invalidate(self._h))
-        self._legal_fresh = self._slab_fresh = False
+        self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
 
 def rows_to_onehot(rows):
@@ -511,7 +521,7 @@ def get_moves(hands, lasts, want_ids=True, row_capacity=None, native_joker_kicke
 def auto_choose(hands, lasts, left, role, want_stats=False):
     """RuleBasedModel.choose for n independent queries (what server/core.py:80-87 calls on a payload): hands / lasts
     int8 [n,15|16] (last all-zero = lead), left int [n,3] = cards left of role 0 up / 1 lord / 2 down, role int [n].
-    Returns int32[n] canonical action ids (0 = pass, -1 = invalid query) (and int64 [n,2] {combinations, nodes})."""
+    Returns int32[n] canonical action ids (0 = pass, -2 = invalid query) (and int64 [n,2] {combinations, nodes})."""
     L = _lib.lib()
     dev = _require_gpu(hands.device)
 

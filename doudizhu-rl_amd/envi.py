@@ -74,6 +74,13 @@ class Env:
         prevprev = self.arr2cards(self.recent_handout[(role + 1) % 3].astype(int))
         return [list(prev), list(prevprev)]
 
+    def get_last_outcards(self):
+        """native get_last_outcards(): the cards the actor has to beat, as ranks 3..17 -- empty when it leads.  Its one
+        caller in the reference feeds it to get_mask as `last_cards` (rule_based/utils/utils.py:195-197), i.e. it is the
+        `last` of valid_actions (envi.py:103-109): the previous player's handout, else the one before, else nothing."""
+        prev, prevprev = self.get_last_two_cards()
+        return np.asarray(prev if len(prev) else prevprev, dtype=int)
+
     def get_state_prob(self):
         """native get_state_prob() (envi.py:94): 120 floats, reshaped (2,15,4) by `face` -- prob planes spec v1."""
         return self._b.observe(0)[0, 2:4].reshape(120).cpu().numpy()
@@ -132,7 +139,8 @@ class Env:
         (decomposer spec v1)."""
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        r, _ = self._step(self._b.auto_choose(0b111), STEP_IDS)
+        ids = self._b.auto_choose(0b111)
+        r, _ = self._step(ids, STEP_IDS)  # (an id the rule agent could not produce -- DDZ_AUTO_INVALID -- raises here)
         cards = self.arr2cards(self.recent_handout[role].astype(int))
         return cards, r, None
 

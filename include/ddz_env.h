@@ -33,7 +33,9 @@ extern "C" {
 #define DDZ_NFIELDS 11
 #define DDZ_TRAJ_BYTES 32
 /* slab list layout: rows per table.  497 = the largest legal list of any hand of <= 20 cards, proven by exhaustive
- * enumeration (tools/max_legal_bound.c; 521 with the joker-kicker rule set); smaller strides are DDZ_EINVAL. */
+ * enumeration of every 20-card hand (tools/max_legal_bound.c, tests/test_rules_bounds.py); the joker-kicker rule set
+ * adds at most 24 rows to a list and the same exhaustive run (built with -DDDZ_JK_RULES) proves its maximum too: also 497 (the worst hands hold no jokers).
+ * Smaller strides are DDZ_EINVAL. */
 #define DDZ_SLAB_MIN_STRIDE 512
 
 /* error codes */
@@ -60,7 +62,9 @@ enum { DDZ_F_HAND0 = 0, DDZ_F_HIST0 = 3, DDZ_F_RECENT0 = 6, DDZ_F_TAKEN = 9, DDZ
                              against the legal segment; no match -> illegal flag, table untouched       */
 #define DDZ_STEP_IDS 3    /* sel = const int32_t[T] canonical action ids (index into card.py:get_action_space();
                              what ddz_auto_choose_state writes, or the arg-max of a policy head over
-                             ddz_legal_mask), validated like ROWS; -1 = engine RNG for that table (RANDOM)  */
+                             ddz_legal_mask), validated like ROWS; -1 = engine RNG for that table (RANDOM);
+                             any other value that is no action id (DDZ_AUTO_INVALID) -> illegal flag         */
+#define DDZ_AUTO_INVALID (-2) /* ddz_auto_choose[_state]: the query was invalid (no combo, role > 2, > 20 cards)   */
 
 /* face variants (envi.py:87-96, :165-178, :182-198, :202-217) -> planes P = 4, 7, 9, 6 */
 #define DDZ_FACE_ENV 0
@@ -147,7 +151,8 @@ int ddz_policy_step_slab(ddz_env_t* env, const float* q, double epsilon, int32_t
  * the variable-length lists as its own cheap pass (two small launches), so that ddz_step_slab / ddz_rollout_random
  * never wait on a scan over all tables: legal lists in CSR order cost ddz_step_slab + this instead of ddz_legal +
  * ddz_step.  A list index is the same in both layouts (ddz_select's choice feeds ddz_step_slab CHOICE).  Rows beyond
- * row_capacity are dropped and status bit 1 is raised.                                                             */
+ * row_capacity are dropped and status bit 1 is raised; the offsets written are clamped to row_capacity, so every
+ * segment [offsets[t], offsets[t+1]) stays inside rows_out (truncated lists are shorter or empty, never out of bounds). */
 int ddz_slab_to_csr(ddz_env_t* env, const int32_t* counts, const int8_t* rows, const int32_t* ids, int64_t stride,
                     int32_t* offsets, int8_t* rows_out, int32_t* ids_out, int64_t row_capacity, void* stream);
 
@@ -251,7 +256,10 @@ int ddz_pack_trajectory(int device_id, const uint8_t* traj, int64_t n_records, u
  *     merge a policy's own ids into the -1 slots first.
  *   ddz_auto_choose: the same for n independent queries (server/core.py:80-87 calls choose() on a payload):
  *     hands / lasts int8[n][16] (byte 15 ignored, `last` all-zero = lead), info u8[n][4] = cards left of role 0, 1, 2
- *     (envi.py:23 `left`) and the acting role; an invalid query (no combo, role > 2, more than 20 cards) yields -1.
+ *     (envi.py:23 `left`) and the acting role; an invalid query (no combo, role > 2, more than 20 cards) yields
+ *     DDZ_AUTO_INVALID (-2: unlike -1 it is never taken for "engine RNG" by DDZ_STEP_IDS) and status bit 2 of the handle.
+ *   Both entry points may be issued on any stream, also concurrently on several streams of one handle: every launch has
+ *   its own work-distribution word, zeroed on its stream (nothing for the caller to initialise or re-arm).
  *   stats (may be NULL): int64[n][2] = {combinations scored, search nodes} of the FULL enumeration per table / query.
  *     With stats == NULL the search is an exact branch and bound (subtrees whose score bound is strictly
  *     below a score already reached are skipped): the same ids from about a tenth of the nodes, 3x faster.          */
@@ -260,6 +268,13 @@ int ddz_auto_choose(int device_id, const int8_t* hands, const int8_t* lasts, con
                     int32_t* ids, int64_t* stats, void* stream);
 /* test hook: 2 * cards_value (rule_based/utils/evaluator.py:10-47) of every action id, int8[DDZ_NUM_ACTIONS] */
 int ddz_debug_cards_value(int device_id, int8_t* out, void* stream);
+/* test hook: ddz_auto_choose_state with an explicit kernel: 1 = the sequential full-enumeration walk (cross-check),
+ * 2 = the lane-parallel branch-and-bound kernel ddz_auto_choose_state always uses.  Same ids by construction.   */
+int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
+/* test hook: launch geometry of a handle (tables per wavefront 1..64, 0 = keep; block-cooperative one-table-per-wave
+ * form of ddz_step_slab 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads
+ * no environment variables.                                                                                      */
+int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */

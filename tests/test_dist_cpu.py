@@ -108,3 +108,20 @@ def test_gather_without_process_group_is_identity():
     assert ddist.gather_trajectories(t) is t
     with pytest.raises(ValueError):
         ddist.gather_trajectories(torch.zeros((3, 4, 31), dtype=torch.uint8))
+
+
+def test_bench_self_spawn_is_loud_without_gpus():
+    """`python bench.py --gpus 2` as the driver types it (no launcher, no WORLD_SIZE): bench.py starts its ranks itself
+    (spawn_ranks -> torch.distributed.run children).  In this container there is no GPU, so the ranks must fail -- and
+    the launcher must pass that on as a non-zero exit and print no JSON line (never a green-looking run)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the rehearsal test in test_gpu_parity.py covers the launcher")
+    env_ = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rehearse", "--tables", "64",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env_)
+    assert p.returncode != 0
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node 2" in p.stderr   # the launcher announced itself
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -435,17 +435,8 @@ def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids, tpw
     choices, done / r / illegal, trajectory records, states, lists and `face` bit-identical, every iteration; one table
     per wave (wave 0 of a block runs the block's lane-parallel phases) and several chunkings of 16-table chunks (the
     fused kernel writes `face` before the lists in half of its waves and after them in the other half)."""
-    import os
     T = 3000
-    old = os.environ.get("DDZ_TPW")
-    os.environ["DDZ_TPW"] = str(tpw)
-    try:
-        a = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
-    finally:
-        if old is None:
-            os.environ.pop("DDZ_TPW")
-        else:
-            os.environ["DDZ_TPW"] = old
+    a = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids, _debug_tables_per_wave=tpw)  # ddz_debug_set_geometry
     b = pkg.BatchedEnv(T, seed=41, device=_dev(), want_ids=want_ids)
     a.reset(); b.reset()
     a.legal_slab(); b.legal_slab()
@@ -968,19 +959,14 @@ def test_bench_two_ranks_rehearsal_gathers_the_union(pkg):
     gathered equal a single-process rollout of the union of the two shards, record for record."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     T, K, W, KX = 512, 40, 10, 30
-    env_ = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"),
-                        "--gpus", "2", "--rehearse", "--strict-exchange", "--tables", str(T), "--steps", str(K),
-                        "--warmup", str(W), "--exchange-steps", str(KX)],
+    env_ = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # exactly what the driver types: no launcher here -- bench.py starts its two ranks itself (spawn_ranks)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rehearse", "--tables", str(T),
+                        "--steps", str(K), "--warmup", str(W), "--exchange-steps", str(KX)],
                        capture_output=True, text=True, timeout=600, env=env_)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -1035,9 +1021,48 @@ def test_slab_to_csr_equals_legal(pkg):
     env.legal_slab()
     total = int(env.counts.sum().item())
     off, rows, ids = env.slab_to_csr(rows_per_table=8)          # a fresh lead has ~73 legal moves: 2400 rows do not fit
-    assert int(off[-1].item()) == total > 2400 and env.status() & 2
+    # truncated: status bit 1, and the offsets are clamped to the capacity (every segment stays inside the buffer)
+    assert total > 2400 and int(off[-1].item()) == 2400 and int(off.max().item()) == 2400 and env.status() & 2
+    off = off.clone()
     off2, rows2, ids2 = env.legal()
     assert torch.equal(rows[:2400], rows2[:2400]) and torch.equal(ids[:2400], ids2[:2400])
+    assert torch.equal(off, off2.clamp(max=2400))
+
+
+def test_slab_to_csr_select_step_slab_runs_no_second_enumeration(pkg, oracle):
+    """The advertised CSR policy loop: step_slab -> slab_to_csr -> q over the CSR rows -> select(q) -> step_slab(CHOICE).
+    select() must take the offsets slab_to_csr just wrote (no ddz_legal, which would also overwrite the slab buffer and
+    force step_slab to enumerate again): legal() / legal_slab() are called exactly once (the initial lists), and states,
+    lists and choices equal the oracle's every iteration."""
+    T = 700
+    env = pkg.BatchedEnv(T, seed=23, device=_dev())
+    ref = oracle.OracleEnv(T, seed=23)
+    env.reset(); ref.reset()
+    calls = {"legal": 0, "legal_slab": 0}
+    real_legal, real_slab = env.legal, env.legal_slab
+
+    def counting(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+
+    env.legal, env.legal_slab = counting("legal", real_legal), counting("legal_slab", real_slab)
+    env.legal_slab()
+    g = torch.Generator().manual_seed(4)
+    for it in range(40):
+        off, rows, ids = env.slab_to_csr(rows_per_table=512)
+        roff, rrows, rids = ref.legal()
+        n = int(roff[-1])
+        assert np.array_equal(off.cpu().numpy(), roff) and np.array_equal(ids[:n].cpu().numpy(), rids)
+        q = torch.randint(-3, 4, (T * 512,), generator=g).float()
+        choice = env.select(q.to(_dev()))
+        want = np.array([int(np.argmax(q[roff[t]:roff[t + 1]].numpy())) if roff[t + 1] > roff[t] else -1 for t in range(T)], np.int32)
+        assert np.array_equal(choice.cpu().numpy(), want)
+        env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+        ref.step(oracle.STEP_CHOICE, want, auto_reset=True)
+        assert np.array_equal(env.state.cpu().numpy(), ref.state), it
+    assert calls == {"legal": 0, "legal_slab": 1} and env.status() == 0
 
 
 @pytest.mark.parametrize("tpw", [1, 5, 16, 23, 40])
@@ -1045,18 +1070,9 @@ def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
     """k_slab handles a wave's tables in lane-parallel chunks of 16: every chunking (one table per wave, a partial chunk,
     exactly one, 16 + 7, 16 + 16 + 8; the last wave ragged) x every mode (CHOICE, ROWS, IDS with engine draws, RANDOM)
     against the oracle: lists, done / r / illegal, trajectory records and the full state after every iteration."""
-    import os
     T, seed = 1003, 40 + tpw
     rng = np.random.default_rng(seed)
-    old = os.environ.get("DDZ_TPW")
-    os.environ["DDZ_TPW"] = str(tpw)
-    try:
-        env = pkg.BatchedEnv(T, seed=seed, device=_dev())
-    finally:
-        if old is None:
-            os.environ.pop("DDZ_TPW")
-        else:
-            os.environ["DDZ_TPW"] = old
+    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), _debug_tables_per_wave=tpw)  # ddz_debug_set_geometry
     ref = oracle.OracleEnv(T, seed=seed)
     env.reset(); ref.reset()
     counts, rows, ids = env.legal_slab()

@@ -31,6 +31,36 @@ def test_497_is_the_exact_maximum_exhaustive(oracle, tmp_path):
     assert int(re.search(r"max legal leads: (\d+)", out).group(1)) == 497
 
 
+def test_joker_kicker_rule_set_maximum_exhaustive(oracle, tmp_path):
+    """The same proof for the optional rule set with the 24 joker-kicker rows (libddz_hip_jk.so: STAGE_CAP, stride and
+    MAX_LEGAL_PER_TABLE are 512 there): the closed form built with -DDDZ_JK_RULES equals the joker-kicker oracle's dense scan on
+    hands that own the extra rows, and its exhaustive maximum over all 20-card hands fits the 512-row slab."""
+    so, exe = str(tmp_path / "bound_jk.so"), str(tmp_path / "bound_jk")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-DDDZ_JK_RULES", "-DMAXLEGAL_NO_MAIN", "-o", so, BOUND_SRC])
+    L = ctypes.CDLL(so)
+    rng = np.random.default_rng(9)
+    deck13 = np.repeat(np.arange(13), 4)
+    with oracle.variant(jk=True):
+        for k in range(600):
+            n = 20 if k % 2 else int(rng.integers(4, 21))
+            h = np.zeros(15, np.int8)
+            h[13] = h[14] = 1                      # both jokers: the hands the extra rows exist for
+            h[:13] = np.bincount(rng.choice(deck13, n - 2, replace=False), minlength=13)
+            if k % 3 == 0:
+                r = int(rng.integers(0, 11))
+                h[r] = max(h[r], 3); h[r + 1] = max(h[r + 1], 3)
+                while h.sum() > 20:
+                    j = int(rng.choice(np.flatnonzero(h[:13] > 0)))
+                    if j not in (r, r + 1):
+                        h[j] -= 1
+            assert L.count_leads(h.ctypes.data_as(ctypes.c_void_p)) == len(oracle.legal(h)), h
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-DDDZ_JK_RULES", "-o", exe, BOUND_SRC])
+    out = subprocess.check_output([exe], timeout=600).decode()
+    assert int(re.search(r"visited: (\d+)", out).group(1)) == 153009740
+    best = int(re.search(r"max legal leads: (\d+)", out).group(1))
+    assert best == 497 <= 512   # the worst hands hold no jokers: the extra rows do not raise the maximum
+
+
 def test_known_worst_20_card_hand(oracle):
     # 4 consecutive triples inside a 12-card straight: a hand that attains the proven maximum
     worst = np.array([1, 1, 1, 1, 1, 3, 3, 3, 3, 1, 1, 1, 0, 0, 0], np.int8)

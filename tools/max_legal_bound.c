@@ -11,8 +11,16 @@
  * get_action_space enumerates (rule_based/utils/card.py:34-159).  tests/test_rules_bounds.py checks this closed form
  * against the oracle's dense scan (ddzo_legal) on random hands and pins the maximum printed here.
  *
- *   gcc -O2 -fopenmp -o /tmp/max_legal_bound tools/max_legal_bound.c && /tmp/max_legal_bound
+ * -DDDZ_JK_RULES: the optional rule set with the 24 joker-kicker rows (quad + both jokers, two consecutive triples + both jokers:
+ * server/mcts/get_moves.py:22-34) -- the two "no joker pair" exclusions (card.py:116,142) are dropped.
+ *
+ *   gcc -O2 -fopenmp [-DDDZ_JK_RULES] -o /tmp/max_legal_bound tools/max_legal_bound.c && /tmp/max_legal_bound
  */
+#ifdef DDZ_JK_RULES
+#define JK_EXCLUDED 0
+#else
+#define JK_EXCLUDED 1
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -51,14 +59,14 @@ int count_leads(const int8_t* c) {
       uint32_t run = ((1u << L) - 1) << s;
       if ((m[3] & run) != run) continue;
       uint32_t k1 = m[1] & ~run;
-      n += binom(popc(k1), L) - (L == 2 && (k1 & JK) == JK ? 1 : 0); /* card.py:116: no joker pair as the 2 kickers */
+      n += binom(popc(k1), L) - (L == 2 && (k1 & JK) == JK ? JK_EXCLUDED : 0); /* card.py:116: no joker pair as the 2 kickers */
       if (L <= 4) n += binom(popc(m[2] & M13 & ~run), L);
     }
   if ((m[1] & JK) == JK) ++n; /* rocket */
   for (int r = 0; r < 13; ++r)
     if (m[4] >> r & 1) {
       uint32_t k1 = m[1] & ~(1u << r);
-      n += c2(popc(k1)) - ((k1 & JK) == JK ? 1 : 0); /* 4+1+1 (card.py:139-143) */
+      n += c2(popc(k1)) - ((k1 & JK) == JK ? JK_EXCLUDED : 0); /* 4+1+1 (card.py:139-143) */
       n += c2(popc(m[2] & M13 & ~(1u << r)));         /* 4+2+2 (card.py:148-153) */
     }
   return n;
