@@ -32,7 +32,7 @@ def cpu_baseline(tables, budget_s):
     """Oracle (CPU port of the same rules/env) on the host cores of this box: one thread, then the tables split over
     EVERY core this process may use (tables are independent), median of three samples."""
     from oracle import oracle
-    cores = max(1, len(os.sched_getaffinity(0)))
+    affinity = max(1, len(os.sched_getaffinity(0)))
     env = oracle.OracleEnv(tables, seed=0)
     env.reset()
     t0 = time.perf_counter()
@@ -42,8 +42,26 @@ def cpu_baseline(tables, budget_s):
     t0 = time.perf_counter()
     plies1, _, _ = env.rollout_random(n1)
     dt1 = time.perf_counter() - t0
-    nm = max(3, min(20000, int(0.25 * budget_s * cores / max(per_iter, 1e-6))))
-    oracle.rollout_random_mt(env, max(3, nm // 8), cores)   # warm the thread pool / page in
+    # how many threads the box really gives this process: the affinity mask can be wider than the container's CPU
+    # quota (a 1-GPU share of a 256-thread host), so the thread count is MEASURED -- a short sample at each candidate
+    # count up to the affinity, the fastest one is used
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    cand = sorted({c for c in (1, 8, 16, 32, 64, 128, affinity, int(quota) if quota else affinity) if 1 <= c <= affinity})
+    sweep = {}
+    oracle.rollout_random_mt(env, 20, cand[-1])   # warm: thread start-up, the oracle's tables paged in on every core
+    for c in cand[1:] or cand:
+        n = max(3, int(0.05 * budget_s * min(c, 32) * (plies1 / dt1) / max(tables, 1)))   # ~0.6 s if it scales to 32
+        t0 = time.perf_counter()
+        p, _, _ = oracle.rollout_random_mt(env, n, c)
+        sweep[c] = p / (time.perf_counter() - t0)
+    cores = max(sweep, key=sweep.get)
+    nm = max(3, min(20000, int(0.1 * budget_s * sweep[cores] / max(tables, 1))))
     rates = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -59,14 +77,16 @@ def cpu_baseline(tables, budget_s):
                     break
     except OSError:
         pass
-    return {"value": rates[1], "unit": "env steps/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
-            "cpu_model": model, "single_core_value": plies1 / dt1, "samples": rates,
+    return {"value": rates[1], "unit": "env steps/s", "cores": cores, "cores_available": os.cpu_count(),
+            "affinity": affinity, "cgroup_cpu_quota": quota, "threads_sweep": {str(k): v for k, v in sweep.items()},
+            "kind": "port", "cpu_model": model, "single_core_value": plies1 / dt1, "samples": rates,
             "python_rules_floor": {"value": 36.0, "unit": "env steps/s", "cores": 1,
                                    "provenance": "SURVEY.md 6: the reference's own rules in Python (card.py action space + "
                                                  "get_mask, ~32 ms per mask) measured in the build container, one core; the "
                                                  "reference does not travel to the GPU box, so this is a recorded figure"},
-            "sample": f"median of 3 x {nm} lock-step iterations x {tables} tables over {cores} threads (affinity of this "
-                      f"process; {os.cpu_count()} logical CPUs on the box), and {n1} iterations on 1 thread in {dt1:.1f} s; "
+            "sample": f"median of 3 x {nm} lock-step iterations x {tables} tables over {cores} threads (the fastest of "
+                      f"{sorted(sweep)} threads tried; affinity {affinity}, {os.cpu_count()} logical CPUs on the box, "
+                      f"cgroup quota {quota}), and {n1} iterations on 1 thread in {dt1:.1f} s; "
                       "oracle/ddz_oracle.c, dense 13,527-row scan per state"}
 
 
@@ -203,6 +223,31 @@ def other_config_legs(pkg, torch, dev):
     out["tables_65536_policy_loop_fused"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
                                              "us_per_iteration": dt / (20 * reps) * 1e6,
                                              "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
+    # configs[2] as SURVEY 8(d) defines it: EnvCooperationSimplify planes + NetCooperationSimplify (net.py:137-150)
+    # randomly initialised (torch.manual_seed(0)), eval mode, greedy arg-max per table over its legal list -- the
+    # network IN the loop (dqn_glue.PolicyLoop: dense per-table GEMMs -> ddz_q_slab -> ddz_policy_step_slab, no host sync)
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    torch.manual_seed(0)
+    net = glue.QNet(6).to(dev).eval()
+    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0)
+    loop.run(3)
+    s0 = env.stats()
+    dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.3, max_reps=64)
+    s1 = env.stats()
+    dtn, repn = timed_loop(lambda: [loop.q_values() for _ in range(5)], sync, min_s=0.15, max_reps=64)
+    dtt, rept = timed_loop(lambda: [loop.fq.tables(loop.face, out=loop.U) for _ in range(5)], sync, min_s=0.15, max_reps=64)
+    dte, repe = timed_loop(lambda: [env.policy_step_slab(loop.q, 0.0, face_variant=3, face_out=loop.face) for _ in range(5)],
+                           sync, min_s=0.05, max_reps=64)
+    rows_eval = s1["legal_rows"] - s0["legal_rows"]
+    out["tables_65536_dqn_inference"] = {
+        "env_steps_per_s": T * 5 * reps / dt, "us_per_iteration": dt / (5 * reps) * 1e6, "iterations": 5 * reps,
+        "us_net": dtn / (5 * repn) * 1e6, "us_net_tables_gemms": dtt / (5 * rept) * 1e6,
+        "us_net_rows_q_slab": (dtn / (5 * repn) - dtt / (5 * rept)) * 1e6, "us_env": dte / (5 * repe) * 1e6,
+        "q_evals_per_s": rows_eval / dt, "mean_legal_moves": rows_eval / max(1, s1["plies"] - s0["plies"]),
+        "dtype_net": "f32", "net": "NetCooperationSimplify-shaped QNet(6 + 1 planes), torch.manual_seed(0), eval()",
+        "loop": "FactorisedQ.tables(face) [plain torch GEMMs] -> ddz_q_slab -> ddz_policy_step_slab(greedy, face = "
+                "EnvCooperationSimplify): every legal action of every table gets its Q value each iteration"}
+    del loop, net
     # the stepping launch alone (uniformly random legal moves drawn in the kernel: every selection is in its list), and
     # the same with the new lists packed to CSR every iteration (what a ragged NN forward over all legal moves consumes)
     dt, reps = timed_loop(lambda: [env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True) for _ in range(20)], sync)

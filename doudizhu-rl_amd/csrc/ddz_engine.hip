@@ -1884,6 +1884,58 @@ __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ st
   choice[t] = best;
 }
 
+// ------------------------------------------------------------------------------------
+// k_q_slab: the per-row stage of the ragged Q forward (game.py:95-104 -> dqn.py:56,67: policy_net(face, actions) over
+// ALL legal actions of a state; net.py:99-101 relu(fc1) -> fc2) over the slab lists, with the first layer factorised
+// per (rank, count) by the host glue (doudizhu-rl_amd/dqn_glue.py FactorisedQ.tables):
+//     q[t][j] = b2 + w2 . relu( sum_{r = 0..14} U[r][t][cnt_r(row j of table t)][:] ),   U f32 [15][T][5][256]
+// One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4l..4l+3: a row costs 15
+// coalesced 1-KB reads of the table's own 75 KB of U (L2-resident across its rows), a 4-wide dot and a wave reduction.
+// The lists are read where ddz_step_slab left them (counts / rows): no CSR, no padding rows, no host sync.
+constexpr int QH = 256;  // hidden units of fc1 (net.py:147)
+__global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, int64_t T, int tpw, const float4* __restrict__ w2,
+                                                 const float* __restrict__ b2, const int32_t* __restrict__ counts,
+                                                 const uint4* __restrict__ rows, int64_t stride, float* __restrict__ q) {
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
+  const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
+  const float4 w = w2[lane];
+  const float bias = b2[0];
+  const int64_t rstride = T * 5 * (QH / 4);  // float4s between ranks
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    int n = (int)rfl((uint32_t)counts[t]);
+    if (n < 0 || n > stride) n = 0;
+    const float4* ut = U + t * 5 * (QH / 4) + lane;
+    const uint4* lrow = rows + t * stride;
+    float* qt = q + t * stride;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int m = n - j0 < 64 ? n - j0 : 64;
+      uint4 myrow = make_uint4(0, 0, 0, 0);
+      if (lane < m) myrow = lrow[j0 + lane];  // one coalesced read of up to 64 rows; row jj is handed round by readlane
+      float res = 0.f;
+      for (int jj = 0; jj < m; ++jj) {
+        const uint32_t r0 = rl(myrow.x, jj), r1 = rl(myrow.y, jj), r2 = rl(myrow.z, jj), r3 = rl(myrow.w, jj);
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+          const uint32_t word = r < 4 ? r0 : r < 8 ? r1 : r < 12 ? r2 : r3;
+          uint32_t c = (word >> (8 * (r & 3))) & 0xFFu;
+          c = c > 4u ? 4u : c;
+          const float4 v = ut[r * rstride + (int64_t)c * (QH / 4)];
+          h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
+        }
+        float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) p += __shfl_xor(p, d);
+        if (lane == jj) res = p + bias;
+      }
+      if (lane < m) qt[j0 + lane] = res;  // coalesced
+    }
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ rows, int64_t n,
                                                     uint32_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -2772,6 +2824,22 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
   hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T * SEL_G + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q,
                      (const int32_t*)nullptr, thr, choice, counts, stride);
+  return check_launch();
+}
+
+int ddz_q_slab(ddz_env_t* e, const float* u, int64_t hidden, const float* w2, const float* b2, const int32_t* counts,
+               const int8_t* rows, int64_t stride, float* q, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(u, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4)) return DDZ_EINVAL;
+  if (!u || !w2 || !b2 || !counts || !rows || !q || hidden != QH || stride < 1) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  // one table per wave up to 16 waves per CU, then consecutive tables per wave (as the stepping kernels)
+  int64_t v = (e->T + 4095) / 4096;
+  const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
+  const int64_t per_block = (int64_t)WPB * tpw;
+  hipLaunchKernelGGL(k_q_slab, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
+                     (const float4*)u, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q);
   return check_launch();
 }
 

@@ -80,3 +80,254 @@ class TransitionAssembler:
 def td_target(transitions, q_next, gamma=0.95):
     """y = r + (1 - done) * gamma * Q_target(s1, a1)  (dqn.py:40-41, config.py:8 GAMMA)."""
     return transitions["reward"] + (~transitions["done"]).float() * gamma * q_next.view(-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# The ragged Q forward of the reference's DQN (net.py:81-102, dqn.py:50-71, game.py:95-104) for T tables at once.
+#
+# The reference evaluates Q(face, action) for EVERY legal action of a state by repeating `face` A times and
+# concatenating the action as one more input plane (net.py:87-90): sum_A rows x (C x 15 x 4) inputs per iteration.
+# Here the first layer is evaluated factorised.  Its five convolutions are linear in their input and look at ONE
+# rank (conv1..4: a (1,k) window, stride 4, on a width-4 input -> one column per rank, net.py:141-144) or ONE
+# thermometer slot (conv_shunzi (15,1), net.py:146), and an action plane is a thermometer of its count vector
+# (envi.py:139-146), so for a rank r that an action takes `cnt` cards of:
+#     maxpool_k conv_k(face + action)[c, r] = max_k ( S_k[t, r, c] + A_k[cnt, c] )          =: Y[t, r, cnt, c]
+# with S = the face part (one GEMM per table, NOT per legal row) and A a 5 x 4 x 256 table of the action-plane
+# weights -- the same for every rank, and cnt = 0 for every rank the action does not touch.  fc1 is linear, so its
+# pre-activation is a sum over the 15 ranks of U[r, t, cnt_r, :] = fc1_r @ Y[t, r, cnt_r, :] (+ the conv_shunzi
+# branch, linear end to end, folded in: a per-table vector and a per-(rank, count) vector).  Per iteration:
+#     tables(face)  -> U [15, T, 5, 256]   dense, fixed shapes, plain torch GEMMs (hipBLASLt) -- no ragged dimension
+#     per legal row -> q = fc2(relu(sum_r U[r, t, cnt_r]))   a 15-way gather-sum + a 256-dot per row
+# The per-row stage runs over the slab lists in the engine (ddz_q_slab: no CSR, no host sync, no padded rows), or
+# over CSR rows with plain torch ops (q_csr: the reference statement, used by the tests).
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+_CONV_CH = 256
+
+
+class QNet(nn.Module):
+    """The reference's Q-network family (net.py:66-150: NetComplicated 5 input planes, NetMoreComplicated 8,
+    NetCooperation 10, NetCooperationSimplify 7), same parameter names and shapes (state_dict-compatible); forward is
+    the literal evaluation of net.py:81-102.  `planes` = planes of `face` (4 / 7 / 9 / 6); + 1 for the action."""
+
+    def __init__(self, planes=6):
+        super().__init__()
+        c = int(planes) + 1
+        self.planes = int(planes)
+        self.conv1 = nn.Conv2d(c, _CONV_CH, (1, 1), (1, 4))
+        self.conv2 = nn.Conv2d(c, _CONV_CH, (1, 2), (1, 4))
+        self.conv3 = nn.Conv2d(c, _CONV_CH, (1, 3), (1, 4))
+        self.conv4 = nn.Conv2d(c, _CONV_CH, (1, 4), (1, 4))
+        self.conv_shunzi = nn.Conv2d(c, _CONV_CH, (15, 1), 1)
+        self.pool = nn.MaxPool2d((1, 4))
+        self.drop = nn.Dropout(0.5)
+        self.fc1 = nn.Linear(_CONV_CH * (15 + 4), 256)
+        self.fc2 = nn.Linear(256, 1)
+
+    def forward(self, face, actions):
+        """face [P,15,4] or [n,P,15,4], actions [n,15,4] -> Q [n,1]  (net.py:81-102)"""
+        if face.dim() == 3:
+            face = face.unsqueeze(0).repeat((actions.shape[0], 1, 1, 1))
+        x = torch.cat((face, actions.unsqueeze(1)), dim=1)
+        y = torch.cat([f(x) for f in (self.conv1, self.conv2, self.conv3, self.conv4)], -1)
+        y = self.pool(y).view(actions.shape[0], -1)
+        z = self.conv_shunzi(x).view(actions.shape[0], -1)
+        h = self.drop(torch.cat([y, z], -1))
+        return self.fc2(F.relu(self.fc1(h)))
+
+
+class FactorisedQ:
+    """Inference form of a QNet: the weight-only tables of the factorisation above, cached until the weights change
+    (refresh() is called automatically when a parameter's version counter moved).  Eval semantics (no dropout)."""
+    KP = 264  # K of the second GEMM: 256 channels + 5 one-hot count columns (the conv_shunzi action part) + 3 pad
+
+    def __init__(self, net, chunk_tables=8192):
+        self.net, self.chunk = net, int(chunk_tables)
+        self.P = net.planes
+        self._ver = None
+        self._ws = {}
+        self.refresh()
+
+    def _versions(self):
+        return tuple(p._version for p in self.net.parameters()) + (next(self.net.parameters()).device,)
+
+    @torch.no_grad()
+    def refresh(self):
+        n, P, H = self.net, self.P, _CONV_CH
+        dev, dt = n.fc1.weight.device, torch.float32
+        C = P + 1
+        convs = (n.conv1, n.conv2, n.conv3, n.conv4)
+        Wf = torch.zeros((P, 4, 4, H), dtype=dt, device=dev)           # [plane, slot j, conv k, channel]
+        A = torch.zeros((5, 4, H), dtype=dt, device=dev)               # [count, conv k, channel]
+        for k, cv in enumerate(convs):
+            w = cv.weight[:, :, 0, :]                                  # [H, C, k+1]
+            Wf[:, : k + 1, k, :] = w[:, :P, :].permute(1, 2, 0)
+            for cnt in range(1, 5):
+                A[cnt, k] = w[:, C - 1, : min(k + 1, cnt)].sum(dim=1)
+        self.Wf = Wf.reshape(P * 4, 4 * H).contiguous()
+        self.bias_f = torch.cat([cv.bias for cv in convs]).contiguous()
+        self.A = A.contiguous()
+        H1 = n.fc1.out_features
+        W1 = n.fc1.weight
+        W1y = W1[:, : 15 * H].reshape(H1, H, 15)                       # input index c * 15 + r (net.py:94 view)
+        W1z = W1[:, 15 * H:].reshape(H1, H, 4)                         # input index c * 4 + w  (net.py:96)
+        Ws = n.conv_shunzi.weight[:, :, :, 0]                          # [H, C, 15]
+        Mz = torch.einsum("ocw,cpr->prwo", W1z, Ws)                    # [C, 15, 4, H1]: conv_shunzi then fc1, composed
+        self.Mz_f = Mz[:P].reshape(P * 60, H1).contiguous()            # face part: one GEMM per table
+        Zr = torch.zeros((15, 5, H1), dtype=dt, device=dev)            # action part per (rank, count)
+        Zr[:, 1:] = Mz[C - 1].cumsum(dim=1)
+        self.base = (n.fc1.bias + torch.einsum("ocw,c->o", W1z, n.conv_shunzi.bias)).contiguous()
+        W2 = torch.zeros((15, self.KP, H1), dtype=dt, device=dev)
+        W2[:, :H] = W1y.permute(2, 1, 0)                               # [r, c, o]
+        W2[:, H:H + 5] = Zr
+        self.W2 = W2.contiguous()
+        self.w2 = n.fc2.weight[0].contiguous()
+        self.b2 = n.fc2.bias.detach().clone()
+        self.H, self.H1 = H, H1
+        self._ver = self._versions()
+        self._ws = {}
+
+    def _workspace(self, Tc, dev):
+        key = (Tc, dev)
+        if key not in self._ws:
+            Y = torch.zeros((15, Tc, 5, self.KP), dtype=torch.float32, device=dev)
+            Y[:, :, :, self.H:self.H + 5] = torch.eye(5, dtype=torch.float32, device=dev)   # one-hot of the count
+            self._ws = {key: (Y, torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev),
+                              torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev))}
+        return self._ws[key]
+
+    @torch.no_grad()
+    def tables(self, face, out=None):
+        """face f32 [T,P,15,4] -> U f32 [15,T,5,H1]: fc1's pre-activation contribution of rank r when the action takes
+        cnt cards of it (the per-table terms -- fc1 bias, the face part of conv_shunzi -- ride on rank 0).  Fixed shapes,
+        no host sync; tables are processed in chunks to bound the workspace."""
+        if self._ver != self._versions():
+            self.refresh()
+        T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
+        if tuple(face.shape[1:]) != (P, 15, 4):
+            raise ValueError(f"face must be [T,{P},15,4]")
+        U = out if out is not None else torch.empty((15, T, 5, H1), dtype=torch.float32, device=face.device)
+        if tuple(U.shape) != (15, T, 5, H1) or not U.is_contiguous():
+            raise ValueError("out must be a contiguous [15,T,5,256] tensor")
+        for t0 in range(0, T, self.chunk):
+            t1 = min(T, t0 + self.chunk)
+            Tc = t1 - t0
+            f = face[t0:t1]
+            Y, S, tmp = self._workspace(self.chunk, face.device)
+            Y, S, tmp = Y[:, :Tc], S[: 15 * Tc], tmp[: 15 * Tc]
+            X = f.permute(2, 0, 1, 3).reshape(15 * Tc, P * 4)          # rank-major rows: (r, t) x (plane, slot)
+            torch.addmm(self.bias_f, X, self.Wf, out=S.view(15 * Tc, 4 * H))
+            for cnt in range(5):
+                torch.add(S, self.A[cnt], out=tmp)
+                Y[:, :, cnt, :H] = tmp.amax(dim=1).view(15, Tc, H)     # max over the four convs = the (1,4) max-pool
+            Uc = U[:, t0:t1]
+            torch.bmm(Y.reshape(15, Tc * 5, self.KP), self.W2, out=Uc.view(15, Tc * 5, H1))
+            Uc[0] += (torch.addmm(self.base, f.reshape(Tc, P * 60), self.Mz_f)).view(Tc, 1, H1)
+        return U
+
+    @torch.no_grad()
+    def q_csr(self, U, rows, offsets):
+        """The per-row stage with plain torch ops over CSR lists (the statement the engine's ddz_q_slab is tested
+        against): rows int8 [N,16] count rows (ddz_legal / ddz_slab_to_csr; rows beyond offsets[T] are padding and get
+        some table's value), offsets int32 [T+1] -> q f32 [N].  No host sync: N is the buffer size."""
+        T = U.shape[1]
+        N = rows.shape[0]
+        pos = torch.arange(N, device=rows.device, dtype=offsets.dtype)
+        seg = torch.searchsorted(offsets[1:].contiguous(), pos, right=True).clamp_(max=T - 1).long()
+        cnt = rows[:, :15].long().clamp_(0, 4)
+        idx = (torch.arange(15, device=rows.device)[None, :] * T + seg[:, None]) * 5 + cnt      # [N,15] into U.view(-1, H1)
+        h = F.embedding_bag(idx, U.view(-1, self.H1), mode="sum")
+        return F.relu(h) @ self.w2 + self.b2
+
+    @torch.no_grad()
+    def q_slab(self, env, U, out=None):
+        """The per-row stage over the engine's slab lists (ddz_q_slab): q f32 [T, stride], entries beyond counts[t]
+        untouched.  Feeds env.policy_step_slab / select_slab."""
+        return env.q_slab(U, self.w2, self.b2, out=out)
+
+
+def ragged_q(net, face, rows, offsets):
+    """Q(face_t, action) for every legal row of every table (dqn.py:56,67: policy_net(face, actions) for all tables at
+    once): face f32 [T,P,15,4], rows int8 [N,16] + offsets int32 [T+1] in CSR order -> q f32 [N].  The factorised
+    tables are cached on the network object and rebuilt when its weights change."""
+    fq = getattr(net, "_ddz_factorised", None)
+    if fq is None:
+        fq = net._ddz_factorised = FactorisedQ(net)
+    return fq.q_csr(fq.tables(face), rows, offsets)
+
+
+class PolicyLoop:
+    """game.py:95-104 for T tables with a Q-network on every seat, one lock-step iteration per step(), nothing on the
+    host in between (no .item(), no size-dependent allocation):
+        face -> FactorisedQ.tables (dense GEMMs) -> ddz_q_slab (q of every legal row, slab layout)
+             -> ddz_policy_step_slab (epsilon-greedy arg-max + apply + next lists + next face, ONE launch)."""
+
+    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True):
+        from .engine import FACE_PLANES
+        if FACE_PLANES[face_variant] != net.planes:
+            raise ValueError("the network's input planes do not match the face variant")
+        self.env, self.fq = env, FactorisedQ(net)
+        self.variant, self.epsilon, self.auto_reset = int(face_variant), float(epsilon), bool(auto_reset)
+        T = env.T
+        self.face = env.observe(self.variant)
+        self.U = torch.empty((15, T, 5, self.fq.H1), dtype=torch.float32, device=env.device)
+        self.q = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=env.device)
+        self.choice = torch.empty(T, dtype=torch.int32, device=env.device)
+        if not env._slab_fresh:
+            env.legal_slab()
+
+    def q_values(self):
+        """q [T, stride] of the current lists (valid in [:, :counts[t]])"""
+        self.fq.tables(self.face, out=self.U)
+        return self.fq.q_slab(self.env, self.U, out=self.q)
+
+    def step(self, traj=None):
+        q = self.q_values()
+        done, r, illegal, _ = self.env.policy_step_slab(q, self.epsilon, face_variant=self.variant, face_out=self.face,
+                                                        choice_out=self.choice, auto_reset=self.auto_reset, traj=traj)
+        return done, r, illegal
+
+    def run(self, n):
+        for _ in range(int(n)):
+            self.step()
+
+
+class Replay:
+    """Ring buffer of transitions on the device (dqn.py:11,22-23: deque(maxlen=REPLAY_SIZE) of tuples)."""
+
+    def __init__(self, size, planes, device):
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)  # noqa: E731
+        self.s0, self.a0, self.s1, self.a1 = z(size, planes, 15, 4), z(size, 15, 4), z(size, planes, 15, 4), z(size, 15, 4)
+        self.r, self.done = z(size), torch.zeros(size, dtype=torch.bool, device=device)
+        self.size, self.n, self.head = size, 0, 0
+
+    def push(self, tr):
+        k = tr["reward"].numel()
+        if k == 0:
+            return
+        if k > self.size:
+            tr = {key: v[-self.size:] for key, v in tr.items()}
+            k = self.size
+        idx = (self.head + torch.arange(k, device=self.r.device)) % self.size
+        self.s0[idx], self.a0[idx], self.s1[idx], self.a1[idx] = tr["s0"], tr["a0"], tr["s1"], tr["a1"]
+        self.r[idx], self.done[idx] = tr["reward"], tr["done"]
+        self.head = (self.head + k) % self.size
+        self.n = min(self.size, self.n + k)
+
+    def sample(self, k):
+        idx = torch.randint(0, self.n, (k,), device=self.r.device)
+        return {"s0": self.s0[idx], "a0": self.a0[idx], "s1": self.s1[idx], "a1": self.a1[idx],
+                "reward": self.r[idx], "done": self.done[idx]}
+
+
+def td_step(policy, target, optimizer, batch, gamma=0.95):
+    """One perceive() update (dqn.py:33-48): y = r + (1 - done) * gamma * Q_target(s1, a1), MSE against
+    Q_policy(s0, a0), one optimizer step.  Returns the loss (a tensor: no host sync)."""
+    with torch.no_grad():
+        y = td_target(batch, target(batch["s1"], batch["a1"]), gamma)
+    loss = F.mse_loss(policy(batch["s0"], batch["a0"]).view(-1), y)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

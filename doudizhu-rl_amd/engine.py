@@ -233,6 +233,26 @@ class BatchedEnv:
                                        _stream(self.device)))
         return out
 
+    def q_slab(self, u, w2, b2, out=None):
+        """Per-row stage of the ragged Q forward over the current slab lists (ddz_q_slab; dqn_glue.FactorisedQ):
+        u f32 [15,T,5,256], w2 f32 [256], b2 f32 [1] (device tensors) -> q f32 [T, stride], valid in [:, :counts[t]]."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        H = int(u.shape[-1])
+        if u.dtype != torch.float32 or tuple(u.shape) != (15, self.T, 5, H) or not u.is_contiguous() or u.device != self.device:
+            raise ValueError("u must be a contiguous float32 [15,T,5,hidden] tensor on the engine's device")
+        w2 = w2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
+        b2 = b2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
+        if w2.numel() != H or b2.numel() != 1:
+            raise ValueError("w2 must be [hidden], b2 [1]")
+        if out is None:
+            out = torch.zeros((self.T, self.slab_stride), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.numel() != self.T * self.slab_stride or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [T, stride] tensor")
+        check(self.lib.ddz_q_slab(self._h, _p(u), H, _p(w2), _p(b2), self._pp["counts"], self._pp["rows"], self.slab_stride,
+                                  _p(out), _stream(self.device)))
+        return out
+
     def legal_onehot(self):
         """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
         self._need_legal()

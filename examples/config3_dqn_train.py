@@ -17,52 +17,18 @@ path feeding a learner, it is not a benchmark of the network.
 """
 import argparse
 import importlib
-import importlib.util
 import math
 import os
 import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 GAMMA, EPS_HIGH, EPS_LOW, DECAY = 0.95, 0.5, 0.01, int((8000 * (2 / 3)) / 5)  # config.py:8-13
 REPLAY_SIZE, BATCH_SIZE, UPDATE_TARGET_EVERY = 20000, 256, 20                   # config.py:11-14
-
-
-class Replay:
-    """Ring buffer of transitions on the device (dqn.py:21-27: deque(maxlen=REPLAY_SIZE))."""
-
-    def __init__(self, size, planes, device):
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)  # noqa: E731
-        self.s0, self.a0, self.s1, self.a1 = z(size, planes, 15, 4), z(size, 15, 4), z(size, planes, 15, 4), z(size, 15, 4)
-        self.r, self.done = z(size), torch.zeros(size, dtype=torch.bool, device=device)
-        self.size, self.n, self.head = size, 0, 0
-
-    def push(self, tr):
-        k = tr["reward"].numel()
-        if k == 0:
-            return
-        if k > self.size:
-            tr = {key: v[-self.size:] for key, v in tr.items()}
-            k = self.size
-        idx = (self.head + torch.arange(k, device=self.r.device)) % self.size
-        self.s0[idx], self.a0[idx], self.s1[idx], self.a1[idx] = tr["s0"], tr["a0"], tr["s1"], tr["a1"]
-        self.r[idx], self.done[idx] = tr["reward"], tr["done"]
-        self.head = (self.head + k) % self.size
-        self.n = min(self.size, self.n + k)
-
-    def sample(self, k):
-        idx = torch.randint(0, self.n, (k,), device=self.r.device)
-        return {"s0": self.s0[idx], "a0": self.a0[idx], "s1": self.s1[idx], "a1": self.a1[idx],
-                "reward": self.r[idx], "done": self.done[idx]}
-
-
-def q_of(net, s, a):
-    return net(torch.cat([s, a[:, None]], dim=1))[:, 0]  # net.py:89-90: the action is one more plane
 
 
 def main(argv=None):
@@ -73,12 +39,9 @@ def main(argv=None):
     a = ap.parse_args(argv)
     pkg = importlib.import_module("doudizhu-rl_amd")
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
-    spec = importlib.util.spec_from_file_location("cfg3", os.path.join(REPO, "examples", "config3_dqn_inference.py"))
-    cfg3 = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(cfg3)
     dev = torch.device("cuda:0")
     torch.manual_seed(a.seed)
-    policy, target = cfg3.QNetSimplify().to(dev), cfg3.QNetSimplify().to(dev)
+    policy, target = glue.QNet(6).to(dev), glue.QNet(6).to(dev)
     target.load_state_dict(policy.state_dict())
     target.eval()
     opt = torch.optim.Adam(policy.parameters(), lr=1e-4)  # dqn.py:19
@@ -86,7 +49,7 @@ def main(argv=None):
     env = pkg.BatchedEnv(T, seed=a.seed, device=dev)
     env.reset()
     asm = glue.TransitionAssembler(T, P, dev)
-    replay = Replay(REPLAY_SIZE, P, dev)
+    replay = glue.Replay(REPLAY_SIZE, P, dev)
     tables = torch.arange(T, device=dev)
     losses, t0, episodes, lord_wins = [], time.perf_counter(), 0, 0
     for it in range(a.iters):
@@ -95,14 +58,12 @@ def main(argv=None):
         face = env.observe(3)
         role = env.role.long()
         lord = role == 1
-        total = int(offsets[-1].item())
+        total = int(offsets[-1].item())                        # (a training loop syncs anyway: replay, logging)
         seg = torch.repeat_interleave(tables, offsets.diff().long(), output_size=total)
         acts = pkg.rows_to_onehot(rows[:total])
-        q = torch.rand(total, device=dev)                      # farmers: random play
-        mine = lord[seg]
-        with torch.no_grad():
-            policy.eval()
-            q[mine] = q_of(policy, face[seg[mine]], acts[mine])
+        policy.eval()
+        qnet = glue.ragged_q(policy, face, rows[:total], offsets)   # Q of every legal row, first layer factorised
+        q = torch.where(lord[seg], qnet, torch.rand(total, device=dev))   # farmers: random play
         greedy_idx = env.select(q, 0.0)
         choice = env.select(q, eps)
         first = offsets[:-1].long()
@@ -115,15 +76,8 @@ def main(argv=None):
             lord_wins += int((done.bool() & (r < 0)).sum())
             env.reset(mask=done)
         if replay.n >= BATCH_SIZE:
-            b = replay.sample(BATCH_SIZE)
-            with torch.no_grad():
-                y = glue.td_target(b, q_of(target, b["s1"], b["a1"]), GAMMA)
-            policy.train()
-            loss = F.mse_loss(q_of(policy, b["s0"], b["a0"]), y)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
-            losses.append(float(loss.detach()))
+            policy.train()                                      # dqn.py:44: the policy net trains with dropout on
+            losses.append(float(glue.td_step(policy, target, opt, replay.sample(BATCH_SIZE), GAMMA)))
         if (it + 1) % UPDATE_TARGET_EVERY == 0:
             target.load_state_dict(policy.state_dict())      # dqn.py:77-79
     torch.cuda.synchronize()

@@ -36,41 +36,29 @@ def main():
     env.legal_slab()
     net = None
     if a.lord == "net":
-        from config3_dqn_inference import QNetSimplify
+        glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
         torch.manual_seed(0)
-        net = QNetSimplify().to(dev).eval()
+        net = glue.QNet(6).to(dev).eval()
+        fq = glue.FactorisedQ(net)
         face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=dev)
+        U = torch.empty((15, T, 5, fq.H1), dtype=torch.float32, device=dev)
+        qbuf = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=dev)
     stats = torch.zeros((T, 2), dtype=torch.int64, device=dev)
     nodes = torch.zeros(2, dtype=torch.int64, device=dev)
 
     @torch.no_grad()
     def lord_ids():
-        """canonical action ids for the tables where the lord is to move (others: ignored)"""
-        counts, rows, ids = env.counts, env.slab_rows(), env.slab_ids()
-        lord = (env.role == 1).nonzero().squeeze(1)
-        if lord.numel() == 0:
-            return None
+        """the Q-network's greedy move as a canonical action id, for every table (only the lord's tables use it): the
+        ragged forward of dqn_glue (dense per-table GEMMs + ddz_q_slab), arg-max by ddz_select_slab; no host sync"""
         env.observe(3, out=face)
-        best = torch.full((T,), -1, dtype=torch.int32, device=dev)
-        n = counts[lord].long()
-        seg = torch.repeat_interleave(lord, n)
-        pos = torch.arange(seg.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(n, 0) - n, n)
-        q = torch.empty(seg.numel(), dtype=torch.float32, device=dev)
-        for lo in range(0, seg.numel(), 131072):
-            hi = min(seg.numel(), lo + 131072)
-            acts = pkg.rows_to_onehot(rows[seg[lo:hi], pos[lo:hi]])
-            q[lo:hi] = net(torch.cat([face[seg[lo:hi]], acts[:, None]], dim=1))[:, 0]
-        qq = torch.full((T, int(n.max())), float("-inf"), device=dev)
-        qq[seg, pos] = q
-        best[lord] = ids[lord, qq[lord].argmax(1)].to(torch.int32)
-        return best
+        q = fq.q_slab(env, fq.tables(face, out=U), out=qbuf)
+        choice = env.select_slab(q)
+        return env.slab_ids().gather(1, choice.clamp(min=0).long()[:, None])[:, 0].to(torch.int32)
 
     def iteration(collect):
         sel = env.auto_choose(0b101, stats=stats if collect else None)
         if net is not None:
-            pol = lord_ids()
-            if pol is not None:
-                sel = torch.where(sel >= 0, sel, pol)
+            sel = torch.where(sel >= 0, sel, lord_ids())
         env.step_slab(sel, pkg.STEP_IDS, auto_reset=True)
         if collect:
             nodes.add_(stats.sum(0))

@@ -233,6 +233,18 @@ int ddz_select(ddz_env_t* env, const float* q, const int32_t* offsets, double ep
 int ddz_select_slab(ddz_env_t* env, const float* q, const int32_t* counts, int64_t stride, double epsilon,
                     int32_t* choice, void* stream);
 
+/* The per-row stage of the reference's ragged Q forward -- policy_net(face, actions) over ALL legal actions of a state
+ * (game.py:95-104, dqn.py:56,67; net.py:99-101 relu(fc1) -> fc2) -- for every table at once, over the slab lists as
+ * ddz_step_slab / ddz_legal_slab left them.  The host glue evaluates the first layer factorised per (rank, count)
+ * (doudizhu-rl_amd/dqn_glue.py FactorisedQ.tables: dense per-table GEMMs, no ragged dimension) into
+ *   u f32 [15][T][5][hidden]: fc1's pre-activation contribution of rank r when the action takes cnt cards of it,
+ * and this writes q[t * stride + j] = b2[0] + w2 . relu(sum_r u[r][t][cnt_r(row j of table t)][:]) for j < counts[t]
+ * (entries beyond counts[t] are left alone) -- what ddz_policy_step_slab / ddz_select_slab take.  No CSR, no padded
+ * rows, no host sync.  hidden must be 256 (net.py:147); w2 f32 [hidden], b2 f32 [1]: DEVICE memory.  fp32; the sum over
+ * the ranks runs r = 0..14 in order (tests: tolerance 1e-5 against the literal nn.Conv2d evaluation).              */
+int ddz_q_slab(ddz_env_t* env, const float* u, int64_t hidden, const float* w2, const float* b2, const int32_t* counts,
+               const int8_t* rows, int64_t stride, float* q, void* stream);
+
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
  * (rule_based/utils/card.py:34-159 order), device memory. */
 int ddz_action_table(int device_id, int8_t* rows, void* stream);
