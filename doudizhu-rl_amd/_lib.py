@@ -53,6 +53,8 @@ SYMBOLS = {
     "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "ddz_select_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "ddz_q_features": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_void_p]),
     "ddz_q_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                              C.c_void_p, C.c_void_p]),
     "ddz_action_table": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
@@ -62,7 +64,7 @@ SYMBOLS = {
                                   C.c_void_p]),
     "ddz_debug_cards_value": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "ddz_debug_auto_choose_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ddz_debug_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ddz_debug_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       n = plan_scan<EM_STAGE, true>(hand, mk_info(EMPTY, 0, 1), hot, lane, o, pk);
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef DDZ_STAMP
+    const unsigned long long tq_enum = __builtin_amdgcn_s_memtime();
+#endif
     if (n > A2_CAND) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
       if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = DDZ_AUTO_INVALID; }
       continue;
@@ -301,6 +304,10 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       else bsw2 |= v << (9 * (r - 14));
     }
 
+#ifdef DDZ_STAMP
+    const unsigned long long tq_sort = __builtin_amdgcn_s_memtime();
+    unsigned long long tq_bounds = tq_sort;
+#endif
     // ---- 1b. branch and bound (off when the caller wants the exact node / combination counts of the full enumeration)
     const bool PRUNE = a.stats == nullptr;
     uint64_t sm0 = 0, sm1 = 0;  // per lowest rank r: the largest candidate whose lowest rank is >= r (bytes)
@@ -322,6 +329,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         const uint64_t m_ = (uint64_t)(v > prev ? v : prev);
         if (r < 8) sm0 |= m_ << (8 * r); else sm1 |= m_ << (8 * (r - 8));
       }
+#ifdef DDZ_STAMP
+      tq_bounds = __builtin_amdgcn_s_memtime();
+#endif
       // a first finished combination: always the largest candidate that fits (few actions = a high score)
       uint64_t gA = hand, gB = 0;
       int gs = 0, gn = 0, gcv = AUTO_NONE, gid = 0, gfrom = A2_NOFROM;
@@ -830,6 +840,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
       g_stamps[16 * t + 6] = n_trips; g_stamps[16 * t + 7] = n_lane_trips;
       for (int k_ = 0; k_ < 5; ++k_) g_stamps[16 * t + 8 + k_] = tsec[k_];
+      g_stamps[16 * t + 13] = tq_enum - tq[0]; g_stamps[16 * t + 14] = tq_sort - tq_enum; g_stamps[16 * t + 15] = tq_bounds - tq_sort;
     }
 #endif
     __builtin_amdgcn_wave_barrier();

@@ -90,6 +90,42 @@ __device__ __forceinline__ uint64_t spread15(uint32_t m) {  // bit r -> bit 4r
   return x;
 }
 
+// ---- wave64 scans / reductions with DPP row operations ------------------------------------------------------------
+// (v_*_dpp reads a neighbour lane's VGPR inside the VALU: ~1 issue slot per step, against an LDS-crossbar round trip of
+// ~100 cycles for every ds_bpermute a __shfl compiles to.)  Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8:
+// a lane whose source is outside its row keeps `identity`), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into
+// rows 2 and 3: an inclusive scan of the 64 lanes in six steps; lane 63 holds the reduction.
+#define DDZ_DPP(identity, v, ctrl, row_mask) __builtin_amdgcn_update_dpp((identity), (v), (ctrl), (row_mask), 0xf, false)
+__device__ __forceinline__ int wave_scan_add(int v) {  // inclusive prefix sum over the lanes
+  v += DDZ_DPP(0, v, 0x111, 0xf);
+  v += DDZ_DPP(0, v, 0x112, 0xf);
+  v += DDZ_DPP(0, v, 0x114, 0xf);
+  v += DDZ_DPP(0, v, 0x118, 0xf);
+  v += DDZ_DPP(0, v, 0x142, 0xa);
+  v += DDZ_DPP(0, v, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v), 63); }
+__device__ __forceinline__ int wave_max_i32(int v) {  // the same value in every lane (wave-uniform)
+  constexpr int ID = (int)0x80000000;
+#define DDZ_STEP(ctrl, rm) { const int o_ = DDZ_DPP(ID, v, ctrl, rm); v = o_ > v ? o_ : v; }
+  DDZ_STEP(0x111, 0xf) DDZ_STEP(0x112, 0xf) DDZ_STEP(0x114, 0xf) DDZ_STEP(0x118, 0xf) DDZ_STEP(0x142, 0xa) DDZ_STEP(0x143, 0xc)
+#undef DDZ_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {  // NaN-free inputs (-inf allowed); wave-uniform result
+  constexpr int NINF_HI = (int)0xFFF00000;
+#define DDZ_STEP(ctrl, rm)                                                                         \
+  {                                                                                                \
+    const int lo_ = DDZ_DPP(0, __double2loint(v), ctrl, rm), hi_ = DDZ_DPP(NINF_HI, __double2hiint(v), ctrl, rm); \
+    const double o_ = __hiloint2double(hi_, lo_);                                                  \
+    v = o_ > v ? o_ : v;                                                                           \
+  }
+  DDZ_STEP(0x111, 0xf) DDZ_STEP(0x112, 0xf) DDZ_STEP(0x114, 0xf) DDZ_STEP(0x118, 0xf) DDZ_STEP(0x142, 0xa) DDZ_STEP(0x143, 0xc)
+#undef DDZ_STEP
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ uint32_t gt_mask(int v) {  // ranks strictly above v (v may be 100)
   return v >= 14 ? 0u : (M15 & ~((2u << v) - 1u));
 }

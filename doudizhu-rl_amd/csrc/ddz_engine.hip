@@ -118,6 +118,8 @@ constexpr int EM_WRITE = 1;   // rows (+ids) into the CSR list at base + running
 constexpr int EM_PICK = 2;    // EM_WRITE + capture the row with list index pk.want
 constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS staging list
 constexpr int EM_MASK = 4;    // bit `id` of the wave's LDS mask (get_mask, utils.py:45-63)
+constexpr int EM_SLAB = 5;    // rows (+ids) built from nib | category straight into the table's slab at base + running index
+                              // (no record rows in LDS, no staging list, no flush pass: what k_slab's list phase uses)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
 constexpr int STAGE_CAP = 500;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
@@ -250,6 +252,14 @@ __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int c
         o.stage[n + pre] = nib | ((uint64_t)cat << 60);
         o.stage_vl[n + pre] = (uint16_t)vl;
         if (IDS) o.stage_ids[n + pre] = (uint16_t)id;
+      }
+    } else if (EM == EM_SLAB) {
+      if (legal) {
+        const int64_t pos = o.base + n + pre;
+        if (pos < o.cap) {  // cap = end of this table's slab
+          o.rows[pos] = unpack_row(nib, (uint32_t)cat);
+          if (IDS) o.ids[pos] = id;
+        }
       }
     } else {
       if (legal) {
@@ -513,10 +523,32 @@ __device__ __forceinline__ uint32_t last_info(uint64_t n1, int c1, uint64_t n2, 
   return mk_info(EMPTY, 0, 1);
 }
 
-// DDZ_STAMP: diagnostic build only (tools/stamp_probe.py): k_rollout accumulates s_memtime
-// deltas per phase into a debug buffer nothing else reads.
+// Phase stamps: s_memtime deltas per phase of a wave, written to a debug buffer nothing else reads -- in -DDDZ_STAMP
+// builds only (tools/stamp_slab.py, tools/stamp_auto.py); in the product build Stamps is an empty object and every
+// mark() / store() compiles to nothing.
 #ifdef DDZ_STAMP
 __device__ unsigned long long* g_stamps = nullptr;  // [T][16]
+template <int N>
+struct Stamps {
+  unsigned long long acc[N] = {}, last = __builtin_amdgcn_s_memtime();
+  __device__ __forceinline__ void mark(int k) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    acc[k] += now - last;
+    last = now;
+  }
+  __device__ __forceinline__ void set(int k, unsigned long long v) { acc[k] = v; }
+  __device__ __forceinline__ void store(int64_t slot, bool writer) const {
+    if (g_stamps && writer)
+      for (int q = 0; q < N; ++q) g_stamps[16 * slot + q] = acc[q];
+  }
+};
+#else
+template <int N>
+struct Stamps {
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void set(int, unsigned long long) {}
+  __device__ __forceinline__ void store(int64_t, bool) const {}
+};
 #endif
 #include "ddz_auto.h"
 #include "ddz_auto2.h"
@@ -559,17 +591,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
   constexpr bool SLAB = (FLAGS & F_SLAB) != 0;
   constexpr bool COUNT = !SLAB && (FLAGS & (F_STEP | F_RESET | F_COUNT)) != 0;
   constexpr bool PICK = ENUM && STEP && MODE == DDZ_STEP_RANDOM;
-#ifdef DDZ_STAMP
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define TACC(k)                                                      \
-  do {                                                               \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
-    tacc[k] += now_ - tlast;                                         \
-    tlast = now_;                                                    \
-  } while (0)
-#else
-#define TACC(k) do { } while (0)
-#endif
+  Stamps<8> stamps;
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * a.tpw;
@@ -601,10 +623,10 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       if (pre_idx >= 0) pre_row = a.rows[(t0 + lane) * a.stride + pre_idx];
     }
   }
-  TACC(0);  // prologue loads issued
+  stamps.mark(0);  // prologue loads issued
   hot_fill<TB>(hot);
   __syncthreads();
-  TACC(1);  // hot fill + barrier
+  stamps.mark(1);  // hot fill + barrier
   if (ENUM && ntab > 0) base = (int64_t)wave_sum(part) + loc0;
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
     uint32_t qinfo = mk_info(EMPTY, 0, 1);
     int cnt = 0;
     Pick pk{-1, 0, 0, 0, 0};
-    TACC(2);  // decode
+    stamps.mark(2);  // decode
     if (ENUM) {
       cnt = (int)rl((uint32_t)cnt_l, i);
       if (lane == 0) a.offsets[t] = (int32_t)base;
@@ -765,7 +787,7 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
         qhand = h1; qinfo = mk_info(EMPTY, 0, 1);
       }
     }
-    TACC(3);  // select + apply + outputs
+    stamps.mark(3);  // select + apply + outputs
     if (changed) {
       if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
       if (COUNT || SLAB) {                     // query of the new actor
@@ -791,15 +813,11 @@ __global__ __launch_bounds__(TB, 4) void k_table(TableArgs a) {
       if (lane == 0) a.slab_counts[t] = n;
       slab_rows += n;
     }
-    TACC(4);  // state store + list of the new state
+    stamps.mark(4);  // state store + list of the new state
     base += cnt;
   }
-#ifdef DDZ_STAMP
-  if (g_stamps && lane == 0 && ntab > 0 && SLAB && STEP) {
-    tacc[5] = ntab;
-    for (int q = 0; q < 8; ++q) g_stamps[16 * t0 + q] = tacc[q];
-  }
-#endif
+  stamps.set(5, (unsigned long long)ntab);
+  stamps.store(t0, lane == 0 && ntab > 0 && SLAB && STEP);
   if (ENUM && ntab > 0 && t0 + ntab == a.T && lane == 0) {
     a.offsets[a.T] = (int32_t)base;
     *a.legal_rows += base;
@@ -865,18 +883,7 @@ struct RolloutArgs {
 
 template <bool IDS, bool TRAJ>
 __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
-#ifdef DDZ_STAMP
-  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-  unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = t_entry;
-#define ACC(k)                                                       \
-  do {                                                               \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
-    acc[k] += now_ - t_last;                                         \
-    t_last = now_;                                                   \
-  } while (0)
-#else
-#define ACC(k) do { } while (0)
-#endif
+  Stamps<12> stamps;
   __shared__ HotTabT<false> hot;
   __shared__ uint64_t s_stage[WPB][STAGE_CAP];
   __shared__ uint16_t s_svl[WPB][STAGE_CAP];
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   asm volatile("" : "+v"(f_bit), "+v"(f_sh), "+v"(f_w0), "+v"(f_w1), "+v"(f_w2), "+v"(f_w3), "+v"(f_grp), "+v"(f_c4), "+v"(f_rk));
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
-    ACC(0);  // prologue (or previous table's tail)
+    stamps.mark(0);  // prologue (or previous table's tail)
     uint4* trow = (uint4*)(a.state + t * STATE_ROW_BYTES);
     uint4 R = Rnext;  // lane f < 11 holds row f of the table for the whole launch
     if (i + 1 < ntab && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + (t + 1) * STATE_ROW_BYTES))[lane];
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       const uint32_t info = rfl((passes >= 2) ? mk_info(EMPTY, 0, 1) : trick);
       const int64_t base = t * a.stride;
       const uint32_t draw = rl(draws, (int)dnext);
-      ACC(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
+      stamps.mark(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
       int n = 0, idx = -1;
       uint4 c = make_uint4(0, 0, 0, 0);  // the chosen row, same value in every lane
       uint64_t snib = 0;                  // ... as a nib, its category and value | len << 8
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         }
         a.counts[t] = n;  // every lane stores the same word: no exec-mask change
         s_rows += n;
-        ACC(5);
+        stamps.mark(5);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
         const int src = __builtin_ctz((uint32_t)__ballot(pre == idx) & okm);
         c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
         else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); ncards = 2; }
         else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); ncards = scat; }
-        ACC(5);  // fast path: list + pick
+        stamps.mark(5);  // fast path: list + pick
       } else {
         const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
         Pick pk{-1, 0, 0, 0, 0};
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           if (lane == 0) atomicOr(a.status, 2);
           n = 0;
         }
-        ACC(2);  // scan (planner + rounds + staging)
+        stamps.mark(2);  // scan (planner + rounds + staging)
         a.counts[t] = n;
         s_rows += n;
         for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           a.rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
           if (IDS) a.ids[base + j] = sid[j];
         }
-        ACC(3);  // flush rows
+        stamps.mark(3);  // flush rows
         if (n > 0) {
           idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83
           const uint64_t e = stage[idx];           // LDS broadcast read
@@ -1037,7 +1044,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           svlv = rfl((uint32_t)svl[idx]);
           ncards = (uint32_t)nib_sum(snib);
         }
-        ACC(10);  // generic pick
+        stamps.mark(10);  // generic pick
       }
       tr1.y |= (uint32_t)n & 0xFFFF;
       if (n <= 0) {
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           }
         }
         if (lane == DDZ_F_RECENT0 + role) R = c;
-        ACC(6);  // row updates
+        stamps.mark(6);  // row updates
         // carried scalars
         const uint64_t hnew = hand - snib;
         if (snib) { trick = scat | (svlv << 8); passes = 0; } else { passes += 1; }
@@ -1064,7 +1071,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
         tr1.w = (uint32_t)idx;
         ply += 1;
         dnext += 1;
-        ACC(7);  // carried scalars
+        stamps.mark(7);  // carried scalars
         if (won) {  // auto-reset: next episode of this table
           if (lane == 0) {  // the wave owns its statistics slot: plain read-modify-write
             int64_t* ws = a.wave_stats + 4 * wave;
@@ -1085,20 +1092,17 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           hc = hn; hn = hp; hp = hnew;
           if (lane == DDZ_F_META) { R.x = (uint32_t)role | (0xFFu << 16); R.y = my_hi | (ply & 0xFFFF); }  // z = episode, w: unchanged
         }
-        ACC(8);  // deal / turn change
+        stamps.mark(8);  // deal / turn change
         if (lane < DDZ_NFIELDS) trow[lane] = R;  // one coalesced 176-byte store
-        ACC(9);  // state store
+        stamps.mark(9);  // state store
       }
       if (TRAJ && lane < 2) tj[lane] = sel4(lane == 0, tr0, tr1);
       if (TRAJ) tj += 2 * a.T;
-      ACC(4);  // pick + apply + deal + state/trajectory stores
+      stamps.mark(4);  // pick + apply + deal + state/trajectory stores
       __builtin_amdgcn_wave_barrier();  // the staging list is reused by the next iteration / table
     }
   }
-#ifdef DDZ_STAMP
-  if (g_stamps && lane == 0 && ntab > 0)
-    for (int q = 0; q < 12; ++q) g_stamps[16 * t0 + q] = acc[q];
-#endif
+  stamps.store(t0, lane == 0 && ntab > 0);
   if (ntab > 0 && lane == 0) {  // each wave owns its statistics slot: no atomics, no barrier
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[3] += s_rows;
@@ -1148,6 +1152,9 @@ struct SlabArgs {
   float4* face;         // [T][P][15] `face` of the NEW states, or null
   int face_variant;
   int coop;             // tpw == 1: wave 0 of a block runs the lane-parallel phases of the block's tables
+  uint32_t* ticket;     // dynamic chunk queue (large batches): [0] next chunk - number of waves, [1] waves that left; or null
+  int chunk;            // ... tables per chunk (<= SLAB_CH)
+  int64_t nchunks;
 };
 constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
 
@@ -1173,8 +1180,7 @@ __device__ __forceinline__ FastLanes fast_lanes(int lane) {
 // the legal list of (hand, info) into the table's slab rows[base ...], ascending canonical id; returns its size
 template <bool IDS, class HT>
 __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t base, int64_t stride, uint4* rows, int32_t* ids,
-                                         uint64_t* stage, uint16_t* svl, uint16_t* sid, const HT& hot, int lane,
-                                         const FastLanes& fl, int32_t* status) {
+                                         const HT& hot, int lane, const FastLanes& fl, int32_t* status) {
   const int lc0 = (int)(info & 0xFF);
   int n;
   if (hand != 0 && lc0 != EMPTY && lc0 <= TRIPLE && !(info & (QF_FROZEN | QF_BADLAST))) {
@@ -1196,20 +1202,15 @@ __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t b
                                  : lane < 29 ? 42 + fl.rr : ID_BIGBANG;
     }
   } else {
-    const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};
+    // every scan round stores its legal rows straight into the slab (compacted positions are consecutive: coalesced
+    // 16-byte stores); nothing is staged in LDS, so there is no flush pass and no LDS round trip behind the scan
+    const Out o{rows, ids, base, base + stride, nullptr, nullptr, nullptr};
     Pick pk{-1, 0, 0, 0, 0};
-    n = plan_scan<EM_STAGE, IDS>(hand, info, hot, lane, o, pk);
-    __builtin_amdgcn_wave_barrier();
-    if (n > STAGE_CAP || n > stride) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
+    n = plan_scan<EM_SLAB, IDS>(hand, info, hot, lane, o, pk);
+    if (n > stride) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c); rows past the slab were dropped
       if (lane == 0 && status) atomicOr(status, 2);
       n = 0;
     }
-    for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
-      const uint64_t e = stage[j];
-      rows[base + j] = unpack_row(e & 0x0FFFFFFFFFFFFFFFull, (uint32_t)(e >> 60));
-      if (IDS) ids[base + j] = sid[j];
-    }
-    __builtin_amdgcn_wave_barrier();  // the staging list is reused by the wave's next table
   }
   return n;
 }
@@ -1274,17 +1275,13 @@ __device__ __forceinline__ bool row_eq(uint4 r, uint4 w) {
 // idle in this phase -- instead of one wave-wide pass per table; only the deal of a finished game, the wave-parallel
 // list search of ROWS / IDS and the lists of the new states remain per-table work.
 constexpr int SLAB_CH = 16;  // 16 tables x 11 rows x 16 B = 2,816 B <= the 4,000-byte staging list of a wave
-static_assert((SLAB_CH * DDZ_NFIELDS + SLAB_CH) * 16 <= STAGE_CAP * 8 && SLAB_CH == 16, "chunk rows + face side records must fit the staging list");
+static_assert(SLAB_CH == 16, "four lanes per table of a chunk in the list search / arg-max");
 
 template <int MODE, bool IDS>
 __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
-#ifdef DDZ_STAMP
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
+  Stamps<8> stamps;
   __shared__ HotTabT<false> hot;
-  __shared__ __attribute__((aligned(16))) uint64_t s_stage[WPB][STAGE_CAP];
-  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
-  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  __shared__ uint4 s_chunk[WPB][SLAB_CH * DDZ_NFIELDS + SLAB_CH];  // per wave: the chunk's state rows + face side records
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
@@ -1293,25 +1290,45 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   const bool coop = a.coop != 0;
   const int64_t tb0 = (int64_t)blockIdx.x * WPB;  // coop: the block's tables
   const int cn = coop ? (tb0 < a.T ? (int)(a.T - tb0 < WPB ? a.T - tb0 : WPB) : 0) : 0;
-  const int64_t tw0 = coop ? tb0 : wave * a.tpw;
-  const int nw = coop ? (wv == 0 ? cn : 0)
+  const int64_t tw0 = coop ? tb0 : a.ticket ? wave : wave * a.tpw;
+  const int nw = coop ? (wv == 0 ? cn : 0) : a.ticket ? 1  // (dynamic chunks: see the chunk loop)
                       : (tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0);  // tables of this wave's lane-parallel phases
   __shared__ uint4 s_share[WPB];  // coop: (hand, combo to beat, live) of the block's tables for the list phase
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
   constexpr bool SEARCH = MODE == DDZ_STEP_ROWS || MODE == DDZ_STEP_IDS;
   constexpr bool DRAWS = MODE == DDZ_STEP_RANDOM || MODE == DDZ_STEP_IDS;
-  uint64_t* stage = s_stage[wv];
-  uint16_t* svl = s_svl[wv];
-  uint16_t* sid = s_sid[IDS ? wv : 0];
-  uint4* srow = (uint4*)stage;  // [SLAB_CH][11]: the chunk's state rows while no list is being staged
+  uint4* srow = s_chunk[wv];  // [SLAB_CH][11]: the chunk's state rows (+ SLAB_CH side records of the face phase)
   const FastLanes fl = fast_lanes(lane);
   const uint32_t LEAD = mk_info(EMPTY, 0, 1);
   int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
   int64_t s_rows = 0;
   const bool face_first = !((wv >> 2) & 1);  // waves wv and wv + 4 share a SIMD
-  for (int c0 = 0; c0 == 0 || c0 < nw; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
-    const int64_t t0 = tw0 + c0;
-    const int ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
+  // Which chunks a wave works on.  Static (small batches, tests): the wave's own tpw tables in chunks of SLAB_CH.  Dynamic
+  // (a.ticket, large batches): chunks of a.chunk tables come from ONE queue -- a wave's first chunk is its own index (no
+  // atomic in front of the cold start), every further one is drawn from the launch's ticket word.  A wave's time is the sum
+  // of its tables' list times, which is heavy-tailed (a 20-card lead costs ten times a follow): with fixed shares the launch
+  // waited for its unluckiest wave (1.76 x the mean wave at 65,536 tables, profiles/r03_notes.md).
+  const bool dyn = a.ticket != nullptr;
+  const int64_t nwaves = (int64_t)gridDim.x * WPB;
+  int64_t cidx = wave;
+  bool first = true;
+  for (int c0 = 0;; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
+    int64_t t0;
+    int ntab;
+    if (dyn) {
+      if (!first) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+        cidx = nwaves + (int64_t)rfl(tk);
+        if (cidx >= a.nchunks) break;
+      }
+      t0 = cidx * a.chunk;
+      ntab = cidx < a.nchunks ? (int)(a.T - t0 < a.chunk ? a.T - t0 : a.chunk) : 0;
+    } else {
+      if (!first && c0 >= nw) break;
+      t0 = tw0 + c0;
+      ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
+    }
     const int nrows = ntab * DDZ_NFIELDS;
     const bool valid = lane < ntab;
     const int64_t t = t0 + lane;  // the table of this lane in the lane-parallel phases
@@ -1330,7 +1347,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       cnt_l = a.counts[t];
       if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
     }
-    if (c0 == 0) hot_fill<TB>(hot);
+    if (first) hot_fill<TB>(hot);
     uint32_t o_done = 0, o_illegal = 0, o_reward = 0;
     bool live = false;         // is there a list to write afterwards
     uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
@@ -1388,7 +1405,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     if (128 + lane < nrows) srow[128 + lane] = R2;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    TACC(0);
+    stamps.mark(0);
     // ---- decode, one table per lane
     uint4* tr = srow + (valid ? lane : 0) * DDZ_NFIELDS;
     const uint4 M = tr[DDZ_F_META];
@@ -1459,7 +1476,7 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       const uint64_t pn = pack_row(c);
       cinfo = info_of_row(pn, (int)(c.w >> 24)) | ((uint32_t)nib_sum(pn) << 24);
     }
-    TACC(2);
+    stamps.mark(2);
     // ---- apply (envi.py:38-43 _update + native step), outputs, trajectory record
     uint4 tr0 = make_uint4(0, 0, 0, 0);
     uint4 tr1 = make_uint4((uint32_t)role, ((uint32_t)A & 0xFFFF) | (ply << 16), episode, 0xFFFFFFFFu);
@@ -1532,22 +1549,20 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     }
     if (coop && valid) s_share[lane] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, live ? 1u : 0u);
     }  // ntab > 0
-    TACC(3);
-    if (c0 == 0) __syncthreads();  // the hot records are in LDS
+    stamps.mark(3);
+    if (first) __syncthreads();  // the hot records are in LDS
     if (MODE == STEP_Q && a.face && face_first && ntab > 0) {
       face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
-      TACC(6);
+      stamps.mark(6);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the rows in LDS are dead from here: the buffer is the staging list again
-    // ---- the lists of the (new) states, straight into the tables' slabs
+    // ---- the lists of the (new) states, straight into the tables' slabs (nothing is staged: the rows in LDS stay valid)
     int n_l = 0;
     if (coop) {
       if (wv < cn) {  // this wave's table of the block
         const uint4 sh = s_share[wv];
         int n = 0;
         if (sh.w) n = slab_list<IDS>((uint64_t)rfl(sh.x) | ((uint64_t)rfl(sh.y) << 32), rfl(sh.z), (tb0 + wv) * a.stride, a.stride, a.rows,
-                                     a.ids, stage, svl, sid, hot, lane, fl, a.status);
+                                     a.ids, hot, lane, fl, a.status);
         if (lane == 0) a.counts[tb0 + wv] = n;
         s_rows += n;
       }
@@ -1556,24 +1571,18 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     while (lv) {
       const int i = __builtin_ctzll(lv);
       lv &= lv - 1;
-      const int n = slab_list<IDS>(rl64(qhand, i), rl(qinfo, i), (t0 + i) * a.stride, a.stride, a.rows, a.ids, stage, svl, sid,
-                                   hot, lane, fl, a.status);
+      const int n = slab_list<IDS>(rl64(qhand, i), rl(qinfo, i), (t0 + i) * a.stride, a.stride, a.rows, a.ids, hot, lane, fl,
+                                   a.status);
       if (lane == i) n_l = n;
       s_rows += n;
     }
     if (MODE == STEP_Q && a.face && !face_first && ntab > 0) {
-      // this half of the waves writes `face` after its lists, from the rows it stored before them, so that at any time
-      // some waves of a SIMD are in the HBM-bound phase and the others in the issue-bound one
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if (lane < nrows) srow[lane] = sp[lane];
-      if (64 + lane < nrows) srow[64 + lane] = sp[64 + lane];
-      if (128 + lane < nrows) srow[128 + lane] = sp[128 + lane];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      // this half of the waves writes `face` after its lists (the rows of the new states are still in LDS), so that at any
+      // time some waves of a SIMD are in the HBM-bound phase and the others in the issue-bound one
       face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      TACC(6);
+      stamps.mark(6);
     }
     if (valid) {  // the per-table outputs: consecutive addresses, one store each
       if (!coop) a.counts[t] = n_l;
@@ -1581,14 +1590,21 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
       if (a.reward) a.reward[t] = (int8_t)o_reward;
       if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
     }
-    TACC(4);
+    stamps.mark(4);
+    first = false;
+    if (dyn && cidx >= a.nchunks) break;  // (a wave beyond the queue: nothing was its own)
   }
-#ifdef DDZ_STAMP
-  if (g_stamps && lane == 0 && (coop ? wv < cn : nw > 0)) {
-    tacc[5] = coop ? 1 : nw;
-    for (int q = 0; q < 8; ++q) g_stamps[16 * (coop ? tb0 + wv : tw0) + q] = tacc[q];
+  if (dyn && lane == 0) {
+    // the last wave to leave re-arms the queue for the next launch (every other wave has made its last draw before it
+    // counted itself out).  The two words belong to the handle: stepping launches of one handle are ordered on one stream
+    // anyway (they move the same state); ddz_create zeroes them.
+    if (atomicAdd(a.ticket + 1, 1u) == (uint32_t)(nwaves - 1)) {
+      atomicExch(a.ticket, 0u);
+      atomicExch(a.ticket + 1, 0u);
+    }
   }
-#endif
+  stamps.set(5, (unsigned long long)(coop ? 1 : nw));
+  stamps.store(coop ? tb0 + wv : tw0, lane == 0 && (coop ? wv < cn : nw > 0));
   if ((coop ? wv < cn : nw > 0) && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
@@ -1603,9 +1619,6 @@ __global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ 
                                                       uint4* __restrict__ rows, int32_t* __restrict__ ids, int64_t stride,
                                                       int32_t* __restrict__ status) {
   __shared__ HotTabT<false> hot;
-  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
-  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
-  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
@@ -1625,8 +1638,7 @@ __global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ 
     const uint64_t hand = rl64(hn, i);
     const uint32_t info = rl(li, i);
     bad = bad || (info & QF_BADLAST);
-    const int m = slab_list<IDS>(hand, info, (t0 + i) * stride, stride, rows, ids, s_stage[wv], s_svl[wv], s_sid[IDS ? wv : 0],
-                                 hot, lane, fl, status);
+    const int m = slab_list<IDS>(hand, info, (t0 + i) * stride, stride, rows, ids, hot, lane, fl, status);
     if (lane == i) n_l = m;
   }
   if (lane < ntab) counts[t0 + lane] = n_l;
@@ -1936,6 +1948,61 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
   }
 }
 
+// k_q_feat: the first layer of the same forward per (table, rank, count) -- conv1..conv4 + the (1,4) max-pool of
+// net.py:92-94 (each conv_k is a (1,k) window, stride 4, on a width-4 input: ONE output column per rank; the pool is the
+// max over the four convs) -- evaluated from `face` alone, for every count cnt = 0..4 an action could take of the rank:
+//     Y[r][t][cnt][c] = max_k ( bias_k[c] + sum_{plane, slot < k} W_k[c][plane][slot] * face[t][plane][r][slot] + A[cnt][k][c] )
+// A[cnt][k][c] = the action plane's thermometer (envi.py:139-146: slots < cnt set) through conv_k.  One block of 256
+// threads = the 256 channels; a thread keeps its channel's weights in registers (P * 10 + 4 + 16 floats) and walks over
+// (table, rank) pairs, whose P float4 of `face` are wave-uniform loads.  Written once, read once by the fc1 GEMM:
+// bound by its 5 x 1 KB of stores per pair.  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
+// reads and writes the [T, 15, 4, 256] conv output ten times; this kernel never materialises it.)
+constexpr int QF_PAIRS = 60;  // (table, rank) pairs per block
+template <int P>
+__global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
+                                               const float* __restrict__ bias, const float* __restrict__ acnt,
+                                               float* __restrict__ y, int64_t ystride) {
+  const int c = threadIdx.x;
+  // this channel's weights: wf [P * 4][4 * 256] (row = plane * 4 + slot, column = k * 256 + c; slots >= k + 1 are zero)
+  float w[P][10];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j <= k; ++j) w[p][q++] = wf[(int64_t)(p * 4 + j) * (4 * QH) + k * QH + c];
+  }
+  float b[4], a[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    b[k] = bias[k * QH + c];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) a[n][k] = acnt[((n + 1) * 4 + k) * QH + c];  // counts 1..4 (count 0 adds nothing)
+  }
+  const int64_t npairs = T * 15;
+  const int64_t p0 = (int64_t)blockIdx.x * QF_PAIRS;
+  const int64_t p1 = p0 + QF_PAIRS < npairs ? p0 + QF_PAIRS : npairs;
+  for (int64_t pr = p0; pr < p1; ++pr) {  // pair = t * 15 + r (the order of `face`'s rows)
+    const int64_t t = pr / 15;
+    const int r = (int)(pr - t * 15);
+    float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float4 x = face[(t * P + p) * 15 + r];  // wave-uniform address
+      s0 += w[p][0] * x.x;
+      s1 += w[p][1] * x.x + w[p][2] * x.y;
+      s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
+      s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+    }
+    float* dst = y + ((int64_t)r * T + t) * 5 * ystride + c;
+    __builtin_nontemporal_store(fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)), dst);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      __builtin_nontemporal_store(fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3])), dst + (n + 1) * ystride);
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ rows, int64_t n,
                                                     uint32_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -2223,6 +2290,8 @@ struct ddz_env {
   bool counts_valid;
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
   int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
+  int slab_chunk;     // k_slab: > 0 = tables per chunk of the dynamic chunk queue (large batches), 0 = fixed shares
+  int cus;            // compute units of the device
 };
 
 namespace {
@@ -2277,6 +2346,21 @@ int launch_table(ddz_env* e, const Io& io, hipStream_t st) {
 int ensure_counts(ddz_env* e, hipStream_t st) {
   if (e->counts_valid) return DDZ_OK;
   return launch_table<F_COUNT, 0>(e, Io{}, st);
+}
+
+// launch geometry of k_slab: fixed shares of tpw tables per wave, or -- large batches -- a resident grid that draws chunks
+// of slab_chunk tables from the handle's queue words (bytes 32..39 of the status block)
+inline dim3 slab_geometry(const ddz_env* e, SlabArgs& a) {
+  a.coop = e->slab_coop;
+  a.ticket = nullptr; a.chunk = 0; a.nchunks = 0;
+  if (e->slab_chunk > 0 && !e->slab_coop) {
+    a.ticket = (uint32_t*)(e->sc.status + 8);
+    a.chunk = e->slab_chunk;
+    a.nchunks = (e->T + a.chunk - 1) / a.chunk;
+    const int64_t want = (a.nchunks + WPB - 1) / WPB, cap = 2 * (int64_t)e->cus;  // two 8-wave blocks per CU are resident
+    return dim3((unsigned)(want < cap ? want : cap));
+  }
+  return dim3((unsigned)e->nblocks);
 }
 }  // namespace
 
@@ -2371,6 +2455,17 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+    e->cus = v;
+  }
+  e->slab_chunk = e->tpw >= 8 ? 8 : 0;  // >= 32,768 tables: chunks of 8 from the dynamic queue
+  {
+    DeviceGuard g(device);
+    const hipError_t r = hipMemset(e->sc.status + 8, 0, 8);  // the queue words of k_slab (the kernel re-arms them)
+    if (r != hipSuccess) { free(e); return hip_fail(r); }
+  }
   *out = e;
   return DDZ_OK;
 }
@@ -2458,9 +2553,8 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
-  a.coop = e->slab_coop;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)e->nblocks), block(TB);
+  const dim3 grid = slab_geometry(e, a), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
   do {                                                                                  \
     if (ids) hipLaunchKernelGGL((k_slab<M, true>), grid, block, 0, st, a);              \
@@ -2493,8 +2587,7 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  a.coop = e->slab_coop;
-  const dim3 grid((unsigned)e->nblocks), block(TB);
+  const dim3 grid = slab_geometry(e, a), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
   e->counts_valid = false;
@@ -2746,15 +2839,18 @@ int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_
 
 // test hook: the launch geometry of a handle's table kernels -- tables per wave (1..64, 0 = keep) and whether k_slab runs
 // the one-table-per-wave block-cooperative form (0 / 1, -1 = keep).  Results never depend on either (tests sweep them).
-int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop) {
+int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int slab_chunk) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1) return DDZ_EINVAL;
+  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1 || slab_chunk < -1 || slab_chunk > SLAB_CH)
+    return DDZ_EINVAL;
   if (tables_per_wave > 0) {
     e->tpw = tables_per_wave;
     e->nblocks = (e->T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
     e->counts_valid = false;  // the scan buffers depend on the geometry
+    e->slab_chunk = 0;        // an explicit share per wave means fixed shares (unless slab_chunk asks otherwise below)
   }
   e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
+  if (slab_chunk >= 0) e->slab_chunk = slab_chunk;
   return DDZ_OK;
 }
 
@@ -2824,6 +2920,26 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
   hipLaunchKernelGGL(k_select, dim3((unsigned)((e->T * SEL_G + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)e->state, e->T, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->gid_base, q,
                      (const int32_t*)nullptr, thr, choice, counts, stride);
+  return check_launch();
+}
+
+int ddz_q_features(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                   const float* acnt, float* y, int64_t y_row_stride, void* stream) {
+  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(y, 4)) return DDZ_EINVAL;
+  if (!face || !wf || !bias || !acnt || !y || n_tables <= 0 || y_row_stride < QH) return DDZ_EINVAL;
+  if (n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  const dim3 grid((unsigned)((n_tables * 15 + QF_PAIRS - 1) / QF_PAIRS)), block(QH);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* f = (const float4*)face;
+  switch (planes) {
+    case 4: hipLaunchKernelGGL(k_q_feat<4>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
+    case 6: hipLaunchKernelGGL(k_q_feat<6>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
+    case 7: hipLaunchKernelGGL(k_q_feat<7>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
+    case 9: hipLaunchKernelGGL(k_q_feat<9>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
+    default: return DDZ_EINVAL;
+  }
   return check_launch();
 }
 

@@ -142,7 +142,7 @@ class FactorisedQ:
     (refresh() is called automatically when a parameter's version counter moved).  Eval semantics (no dropout)."""
     KP = 264  # K of the second GEMM: 256 channels + 5 one-hot count columns (the conv_shunzi action part) + 3 pad
 
-    def __init__(self, net, chunk_tables=8192):
+    def __init__(self, net, chunk_tables=16384):
         self.net, self.chunk = net, int(chunk_tables)
         self.P = net.planes
         self._ver = None
@@ -188,25 +188,35 @@ class FactorisedQ:
         self._ver = self._versions()
         self._ws = {}
 
-    def _workspace(self, Tc, dev):
-        key = (Tc, dev)
+    def _workspace(self, Tc, dev, fused):
+        key = (Tc, dev, fused)
         if key not in self._ws:
+            if len(self._ws) > 3:
+                self._ws.clear()
             Y = torch.zeros((15, Tc, 5, self.KP), dtype=torch.float32, device=dev)
             Y[:, :, :, self.H:self.H + 5] = torch.eye(5, dtype=torch.float32, device=dev)   # one-hot of the count
-            self._ws = {key: (Y, torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev),
-                              torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev))}
+            S = tmp = None
+            if not fused:
+                S = torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev)
+                tmp = torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev)
+            self._ws[key] = (Y, S, tmp)
         return self._ws[key]
 
     @torch.no_grad()
-    def tables(self, face, out=None):
+    def tables(self, face, out=None, fused=None):
         """face f32 [T,P,15,4] -> U f32 [15,T,5,H1]: fc1's pre-activation contribution of rank r when the action takes
         cnt cards of it (the per-table terms -- fc1 bias, the face part of conv_shunzi -- ride on rank 0).  Fixed shapes,
-        no host sync; tables are processed in chunks to bound the workspace."""
+        no host sync; tables are processed in chunks to bound the workspace.
+        fused (default: on a GPU): Y = max-pooled first layer per (rank, table, count) comes from the engine's
+        ddz_q_features in one pass over `face`; fused=False is the same stage in plain torch ops (the statement the
+        kernel is tested against; it reads and writes the [T,15,4,256] conv output ten times)."""
         if self._ver != self._versions():
             self.refresh()
         T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
         if tuple(face.shape[1:]) != (P, 15, 4):
             raise ValueError(f"face must be [T,{P},15,4]")
+        if fused is None:
+            fused = face.is_cuda
         U = out if out is not None else torch.empty((15, T, 5, H1), dtype=torch.float32, device=face.device)
         if tuple(U.shape) != (15, T, 5, H1) or not U.is_contiguous():
             raise ValueError("out must be a contiguous [15,T,5,256] tensor")
@@ -214,15 +224,18 @@ class FactorisedQ:
             t1 = min(T, t0 + self.chunk)
             Tc = t1 - t0
             f = face[t0:t1]
-            Y, S, tmp = self._workspace(self.chunk, face.device)
-            Y, S, tmp = Y[:, :Tc], S[: 15 * Tc], tmp[: 15 * Tc]
-            X = f.permute(2, 0, 1, 3).reshape(15 * Tc, P * 4)          # rank-major rows: (r, t) x (plane, slot)
-            torch.addmm(self.bias_f, X, self.Wf, out=S.view(15 * Tc, 4 * H))
-            for cnt in range(5):
-                torch.add(S, self.A[cnt], out=tmp)
-                Y[:, :, cnt, :H] = tmp.amax(dim=1).view(15, Tc, H)     # max over the four convs = the (1,4) max-pool
+            Y, S, tmp = self._workspace(Tc, face.device, fused)
+            if fused:
+                from .engine import q_features
+                q_features(f.contiguous(), self.Wf, self.bias_f, self.A, Y)
+            else:
+                X = f.permute(2, 0, 1, 3).reshape(15 * Tc, P * 4)      # rank-major rows: (r, t) x (plane, slot)
+                torch.addmm(self.bias_f, X, self.Wf, out=S.view(15 * Tc, 4 * H))
+                for cnt in range(5):
+                    torch.add(S, self.A[cnt], out=tmp)
+                    Y[:, :, cnt, :H] = tmp.amax(dim=1).view(15, Tc, H)  # max over the four convs = the (1,4) max-pool
             Uc = U[:, t0:t1]
-            torch.bmm(Y.reshape(15, Tc * 5, self.KP), self.W2, out=Uc.view(15, Tc * 5, H1))
+            torch.bmm(Y.view(15, Tc * 5, self.KP), self.W2, out=Uc.view(15, Tc * 5, H1))
             Uc[0] += (torch.addmm(self.base, f.reshape(Tc, P * 60), self.Mz_f)).view(Tc, 1, H1)
         return U
 

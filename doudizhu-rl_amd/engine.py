@@ -46,7 +46,8 @@ class BatchedEnv:
     """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
-                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None):
+                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None,
+                 _debug_slab_chunk=None):
         # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
         # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
         self.native_joker_kickers = bool(native_joker_kickers)
@@ -79,9 +80,11 @@ class BatchedEnv:
                                   _p(self.state), self.state.numel(), _p(self.scratch),
                                   self.scratch.numel()))
         self._h = h
-        if _debug_tables_per_wave is not None or _debug_slab_coop is not None:  # test hook: results never depend on it
+        if _debug_tables_per_wave is not None or _debug_slab_coop is not None or _debug_slab_chunk is not None:
+            # test hook: results never depend on the launch geometry
             check(self.lib.ddz_debug_set_geometry(h, int(_debug_tables_per_wave or 0),
-                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop))))
+                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop)),
+                                                  -1 if _debug_slab_chunk is None else int(_debug_slab_chunk)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -466,6 +469,23 @@ def state_prob(known60, size1, size2, device="cuda:0"):
     if n:
         check(L.ddz_state_prob(dev.index, _p(k), _p(sizes), n, _p(out), _stream(dev)))
     return out
+
+
+def q_features(face, wf, bias, acnt, y):
+    """ddz_q_features: first layer of the ragged Q forward per (table, rank, count) from `face` f32 [T,P,15,4] into
+    y f32 [15,T,5,K] (K >= 256; columns >= 256 are left alone).  dqn_glue.FactorisedQ.tables drives it."""
+    L = _lib.lib()
+    dev = _require_gpu(face.device)
+    T, P = int(face.shape[0]), int(face.shape[1])
+    if face.dtype != torch.float32 or tuple(face.shape[2:]) != (15, 4) or not face.is_contiguous():
+        raise ValueError("face must be a contiguous float32 [T,P,15,4] tensor")
+    if y.dtype != torch.float32 or tuple(y.shape[:3]) != (15, T, 5) or not y.is_contiguous() or y.device != dev:
+        raise ValueError("y must be a contiguous float32 [15,T,5,K] tensor on the same device")
+    for w, n in ((wf, P * 4 * 1024), (bias, 1024), (acnt, 5 * 4 * 256)):
+        if w.dtype != torch.float32 or w.numel() != n or not w.is_contiguous() or w.device != dev:
+            raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")
+    check(L.ddz_q_features(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(y), int(y.shape[3]), _stream(dev)))
+    return y
 
 
 def action_table(device="cuda:0", native_joker_kickers=False):

@@ -233,6 +233,18 @@ int ddz_select(ddz_env_t* env, const float* q, const int32_t* offsets, double ep
 int ddz_select_slab(ddz_env_t* env, const float* q, const int32_t* counts, int64_t stride, double epsilon,
                     int32_t* choice, void* stream);
 
+/* First layer of the same forward per (table, rank, count), from `face` alone: conv1..conv4 (net.py:141-144: a (1,k)
+ * window, stride 4, on the width-4 input = one output column per rank) + the (1,4) max-pool (net.py:93-94 = the max over
+ * the four convs), for every count cnt = 0..4 an action could take of that rank (its thermometer, envi.py:139-146, is the
+ * action plane net.py:89-90 appends):
+ *   y[((r * T + t) * 5 + cnt) * y_row_stride + c] = max_k (bias[k][c] + sum_{p, j <= k} wf[p * 4 + j][k * 256 + c] * face[t][p][r][j]
+ *                                                          + acnt[cnt][k][c]),   c < 256
+ * face f32 [T][planes][15][4] (ddz_observe / ddz_policy_step_slab), wf f32 [planes * 4][1024], bias f32 [1024], acnt f32
+ * [5][4][256] (weight-only tables, built by FactorisedQ.refresh from the network's conv weights); planes in {4, 6, 7, 9}.
+ * The host glue multiplies y by fc1 per rank (a batched GEMM) into the u of ddz_q_slab.  Stateless; fp32.            */
+int ddz_q_features(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                   const float* acnt, float* y, int64_t y_row_stride, void* stream);
+
 /* The per-row stage of the reference's ragged Q forward -- policy_net(face, actions) over ALL legal actions of a state
  * (game.py:95-104, dqn.py:56,67; net.py:99-101 relu(fc1) -> fc2) -- for every table at once, over the slab lists as
  * ddz_step_slab / ddz_legal_slab left them.  The host glue evaluates the first layer factorised per (rank, count)
@@ -284,9 +296,10 @@ int ddz_debug_cards_value(int device_id, int8_t* out, void* stream);
  * 2 = the lane-parallel branch-and-bound kernel ddz_auto_choose_state always uses.  Same ids by construction.   */
 int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
 /* test hook: launch geometry of a handle (tables per wavefront 1..64, 0 = keep; block-cooperative one-table-per-wave
- * form of ddz_step_slab 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads
- * no environment variables.                                                                                      */
-int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop);
+ * form of ddz_step_slab 0 / 1, -1 = keep; tables per chunk of ddz_step_slab's dynamic chunk queue 1..16, 0 = fixed
+ * shares per wave, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads no
+ * environment variables.                                                                                         */
+int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_chunk);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */

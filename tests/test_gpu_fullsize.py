@@ -2,6 +2,8 @@
 observe -> per-action values -> select -> step), the same on the last shard of configs[4] (rank 7 of 8: table ids
 7 * 65,536 ...), and configs[3] (rule farmers) -- through size-independent invariants, plus a 2,048-table slice of each
 loop compared bit-exactly with the oracle."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -150,7 +152,9 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         env.legal_slab()
         face = env.observe(variant)
         fq = glue.FactorisedQ(net, chunk_tables=1024)
-        U = fq.tables(face)
+        U = fq.tables(face)                            # first layer by ddz_q_features (one pass over `face`)
+        U_torch = fq.tables(face, fused=False)         # ... and the same stage in plain torch ops
+        assert torch.allclose(U, U_torch, rtol=1e-5, atol=1e-5), float((U - U_torch).abs().max())
         q = env.q_slab(U, fq.w2, fq.b2)
         off, rows, _ = env.slab_to_csr(rows_per_table=512)
         qc = fq.q_csr(U, rows, off)
@@ -160,13 +164,13 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         assert int(valid.sum()) == n
         assert float((q[valid] - qc[:n]).abs().max()) < 1e-5
         assert bool((q[~valid] == 0).all())            # entries beyond counts[t] are left alone
-        # literal evaluation on every 7th row
+        # literal evaluation on every 7th row -- on the CPU (MIOpen would tune a convolution for every new batch size)
         seg = torch.repeat_interleave(torch.arange(T, device=_dev()), counts)
         pick = torch.arange(0, n, 7, device=_dev())
         acts = pkg.rows_to_onehot(rows[:n][pick])
         with torch.no_grad():
-            want = net(face[seg[pick]], acts)[:, 0]
-        assert float((qc[:n][pick] - want).abs().max()) < 1e-5
+            want = copy.deepcopy(net).cpu()(face[seg[pick]].cpu(), acts.cpu())[:, 0]
+        assert float((qc[:n][pick].cpu() - want).abs().max()) < 1e-5
         assert env.status() == 0
 
 
@@ -181,6 +185,7 @@ def test_policy_loop_with_the_q_network_full_size_with_oracle_slice(pkg, oracle)
     T, iters, lo, n = T_FULL, 12, 4096, 2048
     torch.manual_seed(0)
     net = glue.QNet(6).to(_dev()).eval()
+    net_cpu = copy.deepcopy(net).cpu()          # the literal network runs on the CPU (no MIOpen tuning per batch size)
     env = pkg.BatchedEnv(T, seed=77, device=_dev())
     ref = oracle.OracleEnv(n, seed=77, gid_base=lo)
     env.reset(); ref.reset()
@@ -194,11 +199,11 @@ def test_policy_loop_with_the_q_network_full_size_with_oracle_slice(pkg, oracle)
         qcsr = np.concatenate([qs[t, :cnt[t]] for t in range(n)])
         rchoice = ref.select(qcsr)
         if it % 4 == 0:                                          # the values: literal network on the slice's rows
-            seg = torch.from_numpy(np.repeat(np.arange(n), cnt)).to(_dev())
-            acts = pkg.rows_to_onehot(torch.from_numpy(rrows).to(_dev()))
+            seg = torch.from_numpy(np.repeat(np.arange(n), cnt))
+            acts = (torch.from_numpy(rrows[:, :15].astype(np.float32))[:, :, None] > torch.arange(4)[None, None, :]).float()
             with torch.no_grad():
-                want = net(loop.face[lo:lo + n][seg], acts)[:, 0]
-            assert float((torch.from_numpy(qcsr).to(_dev()) - want).abs().max()) < 1e-5
+                want = net_cpu(loop.face[lo:lo + n].cpu()[seg], acts)[:, 0]
+            assert float((torch.from_numpy(qcsr) - want).abs().max()) < 1e-5
             assert np.array_equal(loop.face[lo:lo + n].cpu().numpy().view(np.uint32), ref.observe(3).view(np.uint32))
         done, rew, ill = loop.step()
         assert np.array_equal(loop.choice[lo:lo + n].cpu().numpy(), rchoice), it

@@ -1065,6 +1065,54 @@ def test_slab_to_csr_select_step_slab_runs_no_second_enumeration(pkg, oracle):
     assert calls == {"legal": 0, "legal_slab": 1} and env.status() == 0
 
 
+@pytest.mark.parametrize("chunk", [8, 3, 16])
+def test_slab_api_dynamic_chunk_queue_vs_oracle(pkg, oracle, chunk):
+    """k_slab at large batches: waves draw chunks of tables from one queue (first chunk = the wave's own index, the rest
+    by atomic ticket).  70,001 tables -- more chunks than the 4096 resident waves, a ragged last chunk -- x 10 iterations
+    in every mode against the oracle: lists, outputs, full state; and the queue re-arms itself (status, next launch)."""
+    T, seed = 70001, 900 + chunk
+    rng = np.random.default_rng(seed)
+    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), _debug_slab_chunk=chunk)
+    ref = oracle.OracleEnv(T, seed=seed)
+    env.reset(); ref.reset()
+    env.rollout_random(23); ref.rollout_random(23)      # desynchronised mid-game states, some games already finished
+    counts, rows, ids = env.legal_slab()
+    for it in range(10):
+        roff, rrows, rids = ref.legal()
+        n = np.diff(roff)
+        assert np.array_equal(counts.cpu().numpy(), n)
+        if it % 5 == 0:
+            take = np.arange(env.slab_stride)[None, :] < n[:, None]
+            assert np.array_equal(ids.cpu().numpy()[take], rids) and np.array_equal(rows.cpu().numpy()[take], rrows)
+        mode = (pkg.STEP_CHOICE, pkg.STEP_IDS, pkg.STEP_RANDOM, pkg.STEP_ROWS)[it % 4]
+        choice = (rng.random(T) * np.maximum(n, 1)).astype(np.int32)
+        bad = rng.random(T) < 0.02
+        choice[bad] = -1
+        pick = roff[:-1] + np.clip(choice, 0, np.maximum(n - 1, 0))
+        if mode == pkg.STEP_CHOICE:
+            sel, rsel = torch.from_numpy(choice), choice
+        elif mode == pkg.STEP_IDS:
+            v = np.where(bad, -1, rids[np.minimum(pick, len(rids) - 1)]).astype(np.int32)   # -1: engine RNG
+            sel, rsel = torch.from_numpy(v), v
+        elif mode == pkg.STEP_ROWS:
+            v = rrows[np.minimum(pick, len(rrows) - 1)].copy()
+            v[bad] = 9                                  # no such move: illegal
+            sel, rsel = torch.from_numpy(v), v
+        else:
+            sel, rsel = None, None
+        done, rew, ill = env.step_slab(sel.to(_dev()) if sel is not None else None, mode, auto_reset=it % 3 != 2)
+        rdone, rrew, rill, _ = ref.step({pkg.STEP_CHOICE: oracle.STEP_CHOICE, pkg.STEP_IDS: oracle.STEP_IDS,
+                                         pkg.STEP_RANDOM: oracle.STEP_RANDOM, pkg.STEP_ROWS: oracle.STEP_ROWS}[mode],
+                                        rsel, auto_reset=it % 3 != 2)
+        assert np.array_equal(done.cpu().numpy(), rdone) and np.array_equal(rew.cpu().numpy(), rrew)
+        assert np.array_equal(ill.cpu().numpy(), rill)
+        assert np.array_equal(env.state.cpu().numpy(), ref.state), (it, mode)
+        if it % 3 == 2:
+            env.reset(mask=done); ref.reset(mask=rdone)
+            counts, rows, ids = env.legal_slab()
+    assert env.status() == 0
+
+
 @pytest.mark.parametrize("tpw", [1, 5, 16, 23, 40])
 def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
     """k_slab handles a wave's tables in lane-parallel chunks of 16: every chunking (one table per wave, a partial chunk,
@@ -1118,12 +1166,15 @@ def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
     assert env.status() == 0
 
 
-def test_stepping_calls_are_graph_capturable(pkg):
+@pytest.mark.parametrize("T,chunk", [(777, None), (5000, 1)], ids=["fixed_shares", "dynamic_chunk_queue"])
+def test_stepping_calls_are_graph_capturable(pkg, T, chunk):
     """Every launch of the stepping API goes to the caller's current stream and nothing in it synchronises, so a caller
     can capture its loop in a hipGraph (torch.cuda.graph) and replay it: 3 replays of 8 captured iterations (observe +
-    select_slab + step_slab, and the fused policy step) == the same 24 iterations issued one by one."""
-    T, K = 777, 8
-    a = pkg.BatchedEnv(T, seed=8, device=_dev())
+    select_slab + step_slab, and the fused policy step) == the same 24 iterations issued one by one.  Second case: the
+    dynamic chunk queue of large batches (5000 chunks of one table over 4096 waves: the queue's words are re-armed by
+    the kernel itself, so a replayed launch finds them as the captured one did)."""
+    K = 8
+    a = pkg.BatchedEnv(T, seed=8, device=_dev(), _debug_slab_chunk=chunk)
     b = pkg.BatchedEnv(T, seed=8, device=_dev())
     a.reset(); b.reset(); a.legal_slab(); b.legal_slab()
     q = torch.rand((T, a.slab_stride), dtype=torch.float32, device=_dev())

@@ -1,30 +1,81 @@
-"""One-off soak: a long random rollout on the GPU vs the CPU oracle (all host cores), final state and
-statistics compared bit for bit.  python tools/soak.py [T] [ITERS]   (not part of the test suite)"""
+"""One-off soak of the round-2 kernels against the CPU oracle (all host cores; not part of the test suite):
+  A. k_slab: policy-driven slab loop (CHOICE with random valid indices, occasionally IDS / ROWS), full state compared
+     every iteration;  B. k_auto2: rule agents on all three seats, chosen ids and states compared every iteration.
+python tools/soak.py [T] [ITERS_A] [ITERS_B]"""
 import importlib, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 pkg = importlib.import_module("doudizhu-rl_amd")
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
-for seed, base in ((77, 0), (5, 2 ** 41)):
-    env = pkg.BatchedEnv(T, seed=seed, table_id_base=base, want_ids=False)
-    env.reset()
-    t0 = time.perf_counter()
-    env.rollout_random(K)
-    torch.cuda.synchronize()
-    tg = time.perf_counter() - t0
-    st = env.stats()
-    ref = oracle.OracleEnv(T, seed=seed, gid_base=base)
-    ref.reset()
-    t0 = time.perf_counter()
-    plies, legal, eps = oracle.rollout_random_mt(ref, K, min(16, len(os.sched_getaffinity(0))))
-    tc = time.perf_counter() - t0
-    same = np.array_equal(env.state_export().cpu().numpy(), ref.state)
-    print(f"seed={seed} base={base}: {T} tables x {K} iterations = {plies / 1e6:.1f} M plies; GPU {tg:.2f} s, oracle {tc:.1f} s; "
-          f"state identical: {same}; plies {st['plies']} / {plies}, episodes {st['episodes']} / {eps}, "
-          f"legal rows {st['legal_rows']} / {legal}, status {env.status()}", flush=True)
-    assert same and st["plies"] == plies and st["episodes"] == eps and st["legal_rows"] == legal and env.status() == 0
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+KA = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+KB = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+NT = min(16, len(os.sched_getaffinity(0)))
+cuts = [T * i // NT for i in range(NT + 1)]
+pool = ThreadPoolExecutor(NT)
+
+
+class Shards:
+    """the oracle env split over NT shards (tables are independent; the RNG is keyed by the global table id)"""
+
+    def __init__(self, seed):
+        self.parts = [oracle.OracleEnv(cuts[i + 1] - cuts[i], seed=seed, gid_base=cuts[i]) for i in range(NT)]
+        for p in self.parts:
+            p.reset()
+
+    def map(self, fn):
+        return list(pool.map(fn, range(NT)))
+
+    def state(self):
+        return np.concatenate([p.state for p in self.parts])
+
+
+t0 = time.perf_counter()
+env = pkg.BatchedEnv(T, seed=321)
+env.reset()
+ref = Shards(321)
+counts, rows, ids = env.legal_slab()
+rng = np.random.default_rng(1)
+plies = 0
+for it in range(KA):
+    offs = ref.map(lambda i: ref.parts[i].legal()[0].copy())
+    n = np.concatenate([np.diff(o) for o in offs])
+    assert np.array_equal(counts.cpu().numpy(), n), it
+    choice = (rng.random(T) * np.maximum(n, 1)).astype(np.int32)
+    mode = it % 11
+    if mode == 7:   # canonical ids of the chosen moves
+        sel = np.concatenate([ref.parts[i].ids[offs[i][:-1] + choice[cuts[i]:cuts[i + 1]]] for i in range(NT)]).astype(np.int32)
+        env.step_slab(torch.from_numpy(sel), pkg.STEP_IDS, auto_reset=True)
+        ref.map(lambda i: ref.parts[i].step(oracle.STEP_IDS, sel[cuts[i]:cuts[i + 1]], auto_reset=True))
+    else:
+        env.step_slab(torch.from_numpy(choice), pkg.STEP_CHOICE, auto_reset=True)
+        ref.map(lambda i: ref.parts[i].step(oracle.STEP_CHOICE, choice[cuts[i]:cuts[i + 1]], auto_reset=True))
+    plies += T
+    assert np.array_equal(env.state.cpu().numpy(), ref.state()), it
+print(f"A. slab loop: {T} tables x {KA} iterations = {plies / 1e6:.1f} M plies, state identical every iteration, "
+      f"status {env.status()}, {time.perf_counter() - t0:.0f} s", flush=True)
+
+t0 = time.perf_counter()
+env = pkg.BatchedEnv(T, seed=654)
+env.reset()
+ref = Shards(654)
+env.legal_slab()
+dec = nodes = 0
+st = torch.zeros((T, 2), dtype=torch.int64, device="cuda")
+for it in range(KB):
+    ids = env.auto_choose(0b111, stats=st)     # node counts wanted: the full enumeration
+    idb = env.auto_choose(0b111)               # the product path: exact branch and bound
+    want = np.concatenate(ref.map(lambda i: ref.parts[i].auto_choose(0b111)))
+    assert np.array_equal(ids.cpu().numpy(), want), it
+    assert np.array_equal(idb.cpu().numpy(), want), ("branch and bound", it)
+    dec += int((want >= 0).sum()); nodes += int(st[:, 1].sum())
+    env.step_slab(ids, pkg.STEP_IDS, auto_reset=True)
+    ref.map(lambda i: (ref.parts[i].legal(), ref.parts[i].step(oracle.STEP_IDS, want[cuts[i]:cuts[i + 1]], auto_reset=True)))
+    assert np.array_equal(env.state.cpu().numpy(), ref.state()), it
+s = env.stats()
+print(f"B. rule agents on all seats: {T} tables x {KB} iterations = {dec / 1e6:.2f} M decisions ({nodes / 1e9:.2f} G search nodes), "
+      f"ids (full enumeration AND branch and bound) and states identical every iteration, episodes {s['episodes']}, status {env.status()}, {time.perf_counter() - t0:.0f} s", flush=True)
 print("soak ok")

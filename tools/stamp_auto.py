@@ -13,10 +13,10 @@ os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "stamp.so")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DDDZ_STAMP=1",
                        "-o", lib, os.path.join(csrc, "ddz_engine.hip")])
-os.environ["DDZ_HIP_LIB"] = lib
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+importlib.import_module("doudizhu-rl_amd._lib").use_library(lib)
 pkg = importlib.import_module("doudizhu-rl_amd")
 raw = C.CDLL(lib)
 raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
@@ -41,6 +41,8 @@ s = s[(ids.cpu().numpy() >= 0)]
 print(f"T={T}: {len(s)} decisions, launch {e0.elapsed_time(e1) * 1e3:.0f} us; cycles per decision (s_memtime)")
 for k, nm in enumerate(["staging + sort", "frontier passes", "search"]):
     print(f"  {nm:18s} mean {s[:, k].mean():9.0f}  p50 {np.percentile(s[:, k], 50):9.0f}  p99 {np.percentile(s[:, k], 99):9.0f}  max {s[:, k].max():9.0f}")
+print(f"    staging + sort = enumeration {s[:, 13].mean():.0f} + sort {s[:, 14].mean():.0f} + bounds {s[:, 15].mean():.0f} + greedy "
+      f"{(s[:, 0] - s[:, 13] - s[:, 14] - s[:, 15]).mean():.0f}")
 tot = s[:, :3].sum(1)
 print(f"  total              mean {tot.mean():9.0f}  p99 {np.percentile(tot, 99):9.0f}  max {tot.max():9.0f}   sum/1024 waves {tot.sum() / 1024:.0f}")
 print(f"  frontier items mean {s[:, 3].mean():.0f} max {s[:, 3].max():.0f}; nodes mean {s[:, 4].mean():.0f} max {s[:, 4].max():.0f}; candidates mean {s[:, 5].mean():.0f} max {s[:, 5].max():.0f}")

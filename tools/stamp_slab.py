@@ -14,7 +14,7 @@ os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "stamp.so")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DDDZ_STAMP=1",
                        "-o", lib, os.path.join(csrc, "ddz_engine.hip")])
-os.environ["DDZ_HIP_LIB"] = lib
+importlib.import_module("doudizhu-rl_amd._lib").use_library(lib)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
