@@ -38,7 +38,9 @@ struct AutoArgs {
   int32_t* ids;             // out: canonical action id, -1 = not a rule agent's turn / frozen table, DDZ_AUTO_INVALID = bad query
   int64_t* stats;           // optional: [T][2] {combinations, search nodes}
   int32_t* status;
-  uint32_t* ticket;         // k_auto2: this launch's own zeroed ticket word -- tables are handed out one by one
+  uint32_t* ticket;         // k_auto2: this launch's own zeroed ticket word -- tables are handed out through it
+  const int32_t* order;     // k_auto2, STATE form: the tables to decide, heaviest hands first (k_auto_order), or null
+  const uint32_t* order_hdr;  // ... and its header (AutoOrder: [0..3] bucket sizes, [8] queue length; device words)
   double rp[24];            // round_penalty by min_oppo_cards (rule_based_model.py:57), computed on the host
 };
 

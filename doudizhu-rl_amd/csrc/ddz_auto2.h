@@ -143,6 +143,60 @@ __device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t
   return ub < thr;
 }
 
+// k_auto_order: the tables whose actor is a rule agent, bucketed by the size of its hand (largest first), for k_auto2's
+// queue; every other table gets its -1 here.  Two launches over the tables (the bucket sizes have to be complete before a
+// position can be given out): PASS 0 counts, PASS 1 places.  Inside a bucket the order is whatever the atomics yield --
+// a decision does not depend on when it is made.  Device-scope atomics are per block and class (a few hundred per launch).
+constexpr int AO_CLASSES = 4;
+constexpr int AO_BT = 256;
+struct AutoOrder {  // one slot of the handle's ring (zeroed before PASS 0)
+  uint32_t cnt[AO_CLASSES];   // bucket sizes
+  uint32_t fill[AO_CLASSES];  // PASS 1: positions given out per bucket
+  uint32_t total;             // all buckets (k_auto2's queue length)
+  uint32_t ticket;            // k_auto2's queue head
+  uint32_t pad[6];
+};
+__device__ __forceinline__ int auto_class(int cards) { return cards >= 16 ? 0 : cards >= 13 ? 1 : cards >= 10 ? 2 : 3; }
+template <int PASS>
+__global__ __launch_bounds__(AO_BT) void k_auto_order(const uint8_t* __restrict__ state, int64_t T, int auto_roles,
+                                                      AutoOrder* __restrict__ slot, int32_t* __restrict__ order,
+                                                      int32_t* __restrict__ ids, int64_t* __restrict__ stats) {
+  __shared__ uint32_t s_cnt[AO_CLASSES], s_base[AO_CLASSES];
+  if (threadIdx.x < AO_CLASSES) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * AO_BT + threadIdx.x;
+  int cls = -1;
+  if (t < T) {
+    const uint8_t* row = state + t * STATE_ROW_BYTES;
+    const uint4 meta = *(const uint4*)(row + DDZ_F_META * 16);
+    const int role = meta.x & 0xFF;
+    const bool active = ((meta.y >> 16) & 0xFF) && !((meta.x >> 8) & 0xFF) && role <= 2 && ((auto_roles >> role) & 1);
+    if (active) {
+      cls = auto_class(row[(DDZ_F_HAND0 + role) * 16 + 15]);  // cards left (envi.py:23)
+    } else if (PASS == 0) {
+      ids[t] = -1;  // not a rule agent's turn / frozen table
+      if (stats) { stats[2 * t] = 0; stats[2 * t + 1] = 0; }
+    }
+  }
+  uint32_t rank = 0;
+  if (cls >= 0) rank = atomicAdd(&s_cnt[cls], 1u);
+  __syncthreads();
+  if (PASS == 0) {
+    if (threadIdx.x < AO_CLASSES && s_cnt[threadIdx.x]) {
+      atomicAdd(&slot->cnt[threadIdx.x], s_cnt[threadIdx.x]);
+      atomicAdd(&slot->total, s_cnt[threadIdx.x]);
+    }
+  } else {
+    if (threadIdx.x < AO_CLASSES) {
+      uint32_t b = 0;
+      for (int c = 0; c < (int)threadIdx.x; ++c) b += slot->cnt[c];  // (complete: written by the previous launch)
+      s_base[threadIdx.x] = b + (s_cnt[threadIdx.x] ? atomicAdd(&slot->fill[threadIdx.x], s_cnt[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (cls >= 0) order[s_base[cls] + rank] = (int32_t)t;
+  }
+}
+
 template <bool STATE>
 __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
@@ -159,13 +213,36 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   // launch with its unluckiest wave): *ticket = next table.  The word belongs to THIS launch alone (the host takes it from
   // a ring of device globals and zeroes it on the launch stream, ddz_engine.hip launch_auto): nothing to re-arm, nothing a
   // failed or concurrent launch can leave behind.  Every wave leaves when it draws a ticket >= T: the grid always drains.
+  // Guided shares: a draw takes up to 8 consecutive tables while many are left and one at a time near the end (the size
+  // follows from the previous draw's return value: no extra load).  Device-scope atomics on ONE address serialise at
+  // ~15 ns each on this multi-XCD part (measured, profiles/r03_notes.md): one draw per table would keep that address
+  // busy for 1.0 ms of a 1.5 ms launch at 65,536 tables.
+  // Heaviest first: the size of a decision grows ~1.6 x per card of the hand (a 17-card hand: 2,500 search nodes on
+  // average, 20,000 at most; a 10-card hand: 90) and the largest single decision of a launch lasts as long as a balanced
+  // launch of everything else -- drawn late, it WAS the launch's tail.  With `order` (k_auto_order: the agent's tables
+  // bucketed by hand size, largest hands first) the queue position k means table order[k], so the tail is made of the
+  // cheapest decisions.
+  const int64_t nwaves = (int64_t)gridDim.x * A2_WPB;
+  const int64_t NQ = a.order ? (int64_t)rfl(a.order_hdr[8]) : a.T;  // length of the queue (AutoOrder::total)
+  // ... whose first NH positions are hands of 13 + cards: one per draw (a share of eight of those could be a millisecond)
+  const int64_t NH = a.order ? (int64_t)rfl(a.order_hdr[0]) + (int64_t)rfl(a.order_hdr[1]) : 0;  // AutoOrder::cnt[0] + cnt[1]
+  int64_t tnext = 0, tend = 0;  // queue positions in hand: [tnext, tend)
+  int64_t seen = 0;             // the queue's head as of this wave's last draw
   for (;;) {
     // (taking the next ticket early, to fetch its state rows while this table is decided, was slower: a wave inside a
     // 10^6-cycle decision then holds its next table hostage)
-    uint32_t tk = 0;
-    if (lane == 0) tk = atomicAdd(a.ticket, 1u);
-    const int64_t t = (int64_t)rfl(tk);
-    if (t >= a.T) break;
+    if (tnext >= tend) {
+      int64_t sz = (NQ - seen) / ((a.order ? 4 : 8) * nwaves);
+      sz = (sz < 1 || seen < NH) ? 1 : sz > 8 ? 8 : sz;
+      uint32_t tk = 0;
+      if (lane == 0) tk = atomicAdd(a.ticket, (uint32_t)sz);
+      seen = (int64_t)rfl(tk);
+      if (seen >= NQ) break;
+      tnext = seen;
+      tend = seen + sz < NQ ? seen + sz : NQ;
+    }
+    const int64_t t = a.order ? (int64_t)rfl((uint32_t)a.order[tnext]) : tnext;
+    ++tnext;
     // ---- the query: hand, combo to beat, cards left, acting role (as k_auto)
     uint64_t hand;
     uint32_t linfo;
@@ -243,16 +320,20 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       if (lane == 0) { if (a.status) atomicOr(a.status, 2); a.ids[t] = DDZ_AUTO_INVALID; }
       continue;
     }
-    // per candidate (lane holds entries lane, lane + 64, ...: at most 8): value x 2, fine_mask, lowest rank
+    // per candidate (lane holds entries lane, lane + 64, ...: at most 8): value x 2, fine_mask, lowest rank, cards.
+    // Counting sort by lowest rank: bucket sizes from an LDS histogram (one ds_add per round: the order of the adds does
+    // not matter for a count), bucket starts from one DPP scan, positions inside a bucket from one ballot + mbcnt per rank
+    // that is PRESENT (a hand has candidates on 5-8 lowest ranks, not 15) -- id order is kept inside a bucket.
     constexpr int PER = (A2_CAND + 63) / 64;
     uint64_t e_nib[PER];
     uint32_t e_ci[PER];
-    int e_lr[PER];
-    int cnt_lane = 0;  // lane r: number of candidates whose lowest rank is r
+    int e_lr[PER], e_pos[PER], e_cards[PER];
+    if (lane < 16) W.hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int j = u * 64 + lane;
-      e_lr[u] = 16; e_nib[u] = 0; e_ci[u] = 0;
+      e_lr[u] = 16; e_nib[u] = 0; e_ci[u] = 0; e_pos[u] = 0; e_cards[u] = 0;
       if (u * 64 < n && j < n) {  // (the first test is wave-uniform: whole rounds without candidates are skipped)
         const uint64_t e = W.cn[j];
         const uint64_t nib = e & NIBM;
@@ -264,32 +345,30 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         e_nib[u] = (DDZ_NATIVE_JOKER_KICKERS && sid[j] >= DDZ_NUM_ACTIONS) ? NIBM : nib;
         e_ci[u] = (uint32_t)sid[j] | ((uint32_t)(v2 & 0xFF) << 14) | (el ? 1u << 22 : 0u);
         e_lr[u] = __builtin_ctzll(nib) >> 2;
-      }
-      if (u * 64 < n) {
-#pragma unroll
-        for (int r = 0; r < 15; ++r) {
-          const int c = __popcll(__ballot(e_lr[u] == r));
-          if (lane == r) cnt_lane += c;
-        }
+        e_cards[u] = nib_sum(nib);
+        atomicAdd(&W.hist[e_lr[u]], 1);
       }
     }
-    const int start_lane = wave_incl_scan(lane < 15 ? cnt_lane : 0, lane) - (lane < 15 ? cnt_lane : 0);
-    int run_lane = start_lane;
     __builtin_amdgcn_wave_barrier();  // every entry is in registers: the arrays may be overwritten in sorted order
-    if (lane < 16) W.bstart[lane] = (uint16_t)start_lane;  // lane 15: n
+    const int cnt_lane = lane < 15 ? W.hist[lane] : 0;  // lane r: number of candidates whose lowest rank is r
+    const int start_lane = wave_scan_add(cnt_lane) - cnt_lane;  // lane 15: n
+    const uint32_t present = (uint32_t)__ballot(cnt_lane > 0);
+    int run_lane = start_lane;
+    if (lane < 16) W.bstart[lane] = (uint16_t)start_lane;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       if (u * 64 < n) {
-#pragma unroll
-        for (int r = 0; r < 15; ++r) {
+        for (uint32_t pm = present; pm; pm &= pm - 1) {  // wave-uniform
+          const int r = __builtin_ctz(pm);
           const uint64_t m = __ballot(e_lr[u] == r);
-          if (m) {  // wave-uniform
+          if (m) {
             const int base = (int)rl((uint32_t)run_lane, r);
             const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (e_lr[u] == r) { W.cn[base + pre] = e_nib[u]; W.ci[base + pre] = e_ci[u]; }
+            if (e_lr[u] == r) e_pos[u] = base + pre;
             if (lane == r) run_lane += __popcll(m);
           }
         }
+        if (e_lr[u] < 16) { W.cn[e_pos[u]] = e_nib[u]; W.ci[e_pos[u]] = e_ci[u]; }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -345,19 +424,17 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           else { gB -= 1ull << (4 * pr); v2 = a2_single_v2(pr); el = (q.esingle >> pr) & 1u; id = 1 + pr; }
         } else {
           const int ul = a2_lowrank(gA);
-          const int lo_ = gfrom != A2_NOFROM ? gfrom : a2_bs(bsw0, bsw1, bsw2, ul), hi_ = a2_bs(bsw0, bsw1, bsw2, ul + 1);
+          const int lo_ = gfrom != A2_NOFROM ? gfrom : a2_bs(bsw0, bsw1, bsw2, ul);
           int bk = -1;  // (cards << 10) | (1023 - position): the largest, on ties the first
-          for (int pp = lo_ + lane; pp < hi_; pp += 64) {
-            const uint64_t nb = W.cn[pp];
-            const int k_ = (nib_sum(nb) << 10) | (1023 - pp);
-            if (a2_fits(nb, gA) && k_ > bk) bk = k_;
-          }
+          // the candidates are still in the registers of the sort: bucket ul = the entries whose lowest rank is ul
 #pragma unroll
-          for (int sft = 32; sft >= 1; sft >>= 1) {
-            const int o_ = __shfl_xor(bk, sft);
-            bk = o_ > bk ? o_ : bk;
+          for (int u = 0; u < PER; ++u) {
+            if (u * 64 < n) {
+              const int k_ = (e_cards[u] << 10) | (1023 - e_pos[u]);
+              if (e_lr[u] == ul && e_pos[u] >= lo_ && a2_fits(e_nib[u], gA) && k_ > bk) bk = k_;
+            }
           }
-          bk = (int)rfl((uint32_t)bk);
+          bk = wave_max_i32(bk);  // (DPP: wave-uniform)
           if (bk < 0) { stuck = true; break; }  // (<= 10 cards: the row index may not decrease within a rank)
           const int ps = 1023 - (bk & 1023);
           const uint64_t nb = W.cn[ps];
@@ -469,12 +546,8 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         // lane c holds hist[c]; suffix sums over c = 20 .. 1; tau = the first class (from 20 down) whose suffix sum
         // exceeds the budget (0: everything fits), used = the sum of the classes above it
         const int hc = (lane >= 1 && lane <= 20) ? W.hist[lane] : 0;
-        int suf = hc;  // inclusive suffix sum: sum of hist[lane .. 20]
-#pragma unroll
-        for (int d_ = 1; d_ < 32; d_ <<= 1) {
-          const int o_ = __shfl_down(suf, d_);
-          if (lane + d_ <= 20) suf += o_;
-        }
+        const int pre_ = wave_scan_add(hc);  // inclusive prefix sums (DPP)
+        const int suf = (int)rl((uint32_t)pre_, 63) - pre_ + hc;  // inclusive suffix sum: sum of hist[lane .. 20]
         const uint32_t over = (uint32_t)__ballot(lane >= 1 && lane <= 20 && suf > budget);
         if (over) {
           tau = 31 - __builtin_clz(over);
@@ -505,7 +578,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         if (marginal_partial) {  // members of the marginal class, in order, while their growth still fits
           const bool cand = mine && !leaf && cards == tau;
           const int g = cand ? cnt - 1 : 0;
-          const int gin = wave_incl_scan(g, lane);
+          const int gin = wave_scan_add(g);
           if (cand && gin <= mleft) expand = true;
           // the prefix property: stop at the first member that does not fit
           const uint64_t bad = __ballot(cand && gin > mleft);
@@ -516,7 +589,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           }
         }
         const int oc = mine ? (expand ? cnt : 1) : 0;
-        const int oin = wave_incl_scan(oc, lane);
+        const int oin = wave_scan_add(oc);
         int w = wbase + oin - oc;
         wbase += (int)rl((uint32_t)oin, 63);
         any = any || __ballot(expand) != 0;
@@ -598,12 +671,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
 #define A2T(k) do { } while (0)
 #endif
       if (PRUNE && (trip & 3) == 0) {  // the best score any lane has reached so far
-        double bvw = best.move >= 0 ? best.value : -__builtin_inf();
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-          const double o_ = __shfl_xor(bvw, sft);
-          bvw = o_ > bvw ? o_ : bvw;
-        }
+        const double bvw = wave_max_f64(best.move >= 0 ? best.value : -__builtin_inf());  // (values are never NaN)
         thr = bvw > thr ? bvw : thr;
       }
       bool want_score = false, want_open = false, want_back = false;
@@ -818,18 +886,19 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     tq[3] = __builtin_amdgcn_s_memtime();
 #endif
     // ---- 4. the wave's best: larger value, on ties the smaller order key
-    double bv = best.move >= 0 ? best.value : -__builtin_inf();
-    uint64_t bk = best.move >= 0 ? best_key : ~0ull;
-    int bm = best.move;
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      const double ov = __shfl_xor(bv, sft);
-      const uint64_t ok2 = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(bk >> 32), sft) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)bk, sft);
-      const int om = __shfl_xor(bm, sft);
-      const bool take = om >= 0 && (bm < 0 || ov > bv || (ov == bv && ok2 < bk));
-      if (take) { bv = ov; bk = ok2; bm = om; }
+    // (three DPP reductions: the maximum value, then the smallest key among the lanes that hold it -- high word, low word)
+    int bm = -1;
+    {
+      const bool have = best.move >= 0;
+      const double bvmax = wave_max_f64(have ? best.value : -__builtin_inf());
+      const bool top = have && best.value == bvmax;
+      const uint32_t khi = wave_min_u32(top ? (uint32_t)(best_key >> 32) : 0xFFFFFFFFu);
+      const bool top2 = top && (uint32_t)(best_key >> 32) == khi;
+      const uint32_t klo = wave_min_u32(top2 ? (uint32_t)best_key : 0xFFFFFFFFu);
+      const uint64_t win = __ballot(top2 && (uint32_t)best_key == klo);
+      if (win) bm = (int)rl((uint32_t)best.move, __builtin_ctzll(win));
     }
-    const int nodes = wave_sum(nodes_l), combs = wave_sum(combs_l);
+    const int nodes = wave_sum_i32(nodes_l), combs = wave_sum_i32(combs_l);
     if (lane == 0) {
       a.ids[t] = bm < 0 ? 0 : bm;  // rule_based_model.py:87-89
       if (a.stats) { a.stats[2 * t] = combs; a.stats[2 * t + 1] = nodes; }

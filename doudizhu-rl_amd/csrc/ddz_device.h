@@ -106,12 +106,24 @@ __device__ __forceinline__ int wave_scan_add(int v) {  // inclusive prefix sum o
   return v;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v), 63); }
+__device__ __forceinline__ float wave_sum_f32(float v) {  // the same value in every lane; the order of the adds is fixed
+#define DDZ_STEP(ctrl, rm) v += __int_as_float(DDZ_DPP(0, __float_as_int(v), ctrl, rm));
+  DDZ_STEP(0x111, 0xf) DDZ_STEP(0x112, 0xf) DDZ_STEP(0x114, 0xf) DDZ_STEP(0x118, 0xf) DDZ_STEP(0x142, 0xa) DDZ_STEP(0x143, 0xc)
+#undef DDZ_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ int wave_max_i32(int v) {  // the same value in every lane (wave-uniform)
   constexpr int ID = (int)0x80000000;
 #define DDZ_STEP(ctrl, rm) { const int o_ = DDZ_DPP(ID, v, ctrl, rm); v = o_ > v ? o_ : v; }
   DDZ_STEP(0x111, 0xf) DDZ_STEP(0x112, 0xf) DDZ_STEP(0x114, 0xf) DDZ_STEP(0x118, 0xf) DDZ_STEP(0x142, 0xa) DDZ_STEP(0x143, 0xc)
 #undef DDZ_STEP
   return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {  // wave-uniform
+#define DDZ_STEP(ctrl, rm) { const uint32_t o_ = (uint32_t)DDZ_DPP((int)0xFFFFFFFF, (int)v, ctrl, rm); v = o_ < v ? o_ : v; }
+  DDZ_STEP(0x111, 0xf) DDZ_STEP(0x112, 0xf) DDZ_STEP(0x114, 0xf) DDZ_STEP(0x118, 0xf) DDZ_STEP(0x142, 0xa) DDZ_STEP(0x143, 0xc)
+#undef DDZ_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ double wave_max_f64(double v) {  // NaN-free inputs (-inf allowed); wave-uniform result
   constexpr int NINF_HI = (int)0xFFF00000;

@@ -29,6 +29,7 @@
 //   k_mask    get_mask (utils.py:45-63) of every table as a bit-packed dense mask; k_select segment arg-max /
 //             epsilon-greedy (dqn.py:50-71); k_pack_traj 32-byte -> 8-byte trajectory records; k_export_table.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,9 +54,10 @@ constexpr int F_ENUM = 1, F_STEP = 2, F_RESET = 4, F_COUNT = 8, F_SLAB = 16;
 
 // ------------------------------------------------------------------------------------
 // scratch layout (caller-owned, zero-filled at create)
+constexpr int AUTO_SLOTS = 4;  // ring of k_auto2 queue slots per handle (concurrent launches on several streams)
 struct Layout {
   int64_t T, nblk;
-  int64_t off_counts, off_local, off_blk_tot, off_blk_stats, off_status, bytes;
+  int64_t off_counts, off_local, off_blk_tot, off_blk_stats, off_status, off_auto, auto_slot_bytes, bytes;
 };
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline Layout make_layout(int64_t T) {
@@ -68,6 +70,8 @@ inline Layout make_layout(int64_t T) {
   l.off_blk_tot = o;    o = align_up(o + 2 * l.nblk * 4, 256);
   l.off_blk_stats = o;  o = align_up(o + T * 32, 256);           // one slot per wave (<= T)
   l.off_status = o;     o = align_up(o + 64, 256);
+  l.auto_slot_bytes = align_up(64 + 4 * T, 256);                  // AutoOrder header + order[T]
+  l.off_auto = o;       o = align_up(o + AUTO_SLOTS * l.auto_slot_bytes, 256);
   l.bytes = o;
   return l;
 }
@@ -132,19 +136,9 @@ struct Pick {
 
 #include "ddz_build_table.h"
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(v, d);
-    if (lane >= d) v += y;
-  }
-  return v;
-}
+// (DPP row operations, ddz_device.h: six VALU steps instead of six ds_bpermute round trips; every lane must be active)
+__device__ __forceinline__ int wave_sum(int v) { return wave_sum_i32(v); }
+__device__ __forceinline__ int wave_incl_scan(int v, int) { return wave_scan_add(v); }
 
 // ------------------------------------------------------------------------------------
 // Per-action record table, 32 B per canonical id (433 KB: L2-resident, the hot first
@@ -1152,9 +1146,6 @@ struct SlabArgs {
   float4* face;         // [T][P][15] `face` of the NEW states, or null
   int face_variant;
   int coop;             // tpw == 1: wave 0 of a block runs the lane-parallel phases of the block's tables
-  uint32_t* ticket;     // dynamic chunk queue (large batches): [0] next chunk - number of waves, [1] waves that left; or null
-  int chunk;            // ... tables per chunk (<= SLAB_CH)
-  int64_t nchunks;
 };
 constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
 
@@ -1277,8 +1268,11 @@ __device__ __forceinline__ bool row_eq(uint4 r, uint4 w) {
 constexpr int SLAB_CH = 16;  // 16 tables x 11 rows x 16 B = 2,816 B <= the 4,000-byte staging list of a wave
 static_assert(SLAB_CH == 16, "four lanes per table of a chunk in the list search / arg-max");
 
+#ifndef DDZ_SLAB_WAVES
+#define DDZ_SLAB_WAVES 4  // waves per SIMD the register budget of k_slab allows (5 / 6 spill: measured, not faster)
+#endif
 template <int MODE, bool IDS>
-__global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
+__global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   Stamps<8> stamps;
   __shared__ HotTabT<false> hot;
   __shared__ uint4 s_chunk[WPB][SLAB_CH * DDZ_NFIELDS + SLAB_CH];  // per wave: the chunk's state rows + face side records
@@ -1290,8 +1284,8 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   const bool coop = a.coop != 0;
   const int64_t tb0 = (int64_t)blockIdx.x * WPB;  // coop: the block's tables
   const int cn = coop ? (tb0 < a.T ? (int)(a.T - tb0 < WPB ? a.T - tb0 : WPB) : 0) : 0;
-  const int64_t tw0 = coop ? tb0 : a.ticket ? wave : wave * a.tpw;
-  const int nw = coop ? (wv == 0 ? cn : 0) : a.ticket ? 1  // (dynamic chunks: see the chunk loop)
+  const int64_t tw0 = coop ? tb0 : wave * a.tpw;
+  const int nw = coop ? (wv == 0 ? cn : 0)
                       : (tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0);  // tables of this wave's lane-parallel phases
   __shared__ uint4 s_share[WPB];  // coop: (hand, combo to beat, live) of the block's tables for the list phase
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
@@ -1303,32 +1297,14 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
   int s_ply = 0, s_eps = 0, s_lord = 0, s_up = 0;
   int64_t s_rows = 0;
   const bool face_first = !((wv >> 2) & 1);  // waves wv and wv + 4 share a SIMD
-  // Which chunks a wave works on.  Static (small batches, tests): the wave's own tpw tables in chunks of SLAB_CH.  Dynamic
-  // (a.ticket, large batches): chunks of a.chunk tables come from ONE queue -- a wave's first chunk is its own index (no
-  // atomic in front of the cold start), every further one is drawn from the launch's ticket word.  A wave's time is the sum
-  // of its tables' list times, which is heavy-tailed (a 20-card lead costs ten times a follow): with fixed shares the launch
-  // waited for its unluckiest wave (1.76 x the mean wave at 65,536 tables, profiles/r03_notes.md).
-  const bool dyn = a.ticket != nullptr;
-  const int64_t nwaves = (int64_t)gridDim.x * WPB;
-  int64_t cidx = wave;
+  // (A dynamic queue of chunks -- waves drawing their next 4..16 tables by atomic ticket, so that the launch does not wait
+  // for the unluckiest wave, whose 16 lists cost 1.76 x the mean -- was built and measured in round 3: 112-245 us instead
+  // of 34 us.  Thousands of device-scope atomics on ONE address serialise at ~18 ns each on this multi-XCD part
+  // (profiles/r03_notes.md); fixed shares it is.)
   bool first = true;
-  for (int c0 = 0;; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
-    int64_t t0;
-    int ntab;
-    if (dyn) {
-      if (!first) {
-        uint32_t tk = 0;
-        if (lane == 0) tk = atomicAdd(a.ticket, 1u);
-        cidx = nwaves + (int64_t)rfl(tk);
-        if (cidx >= a.nchunks) break;
-      }
-      t0 = cidx * a.chunk;
-      ntab = cidx < a.nchunks ? (int)(a.T - t0 < a.chunk ? a.T - t0 : a.chunk) : 0;
-    } else {
-      if (!first && c0 >= nw) break;
-      t0 = tw0 + c0;
-      ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
-    }
+  for (int c0 = 0; first || c0 < nw; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
+    const int64_t t0 = tw0 + c0;
+    const int ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
     const int nrows = ntab * DDZ_NFIELDS;
     const bool valid = lane < ntab;
     const int64_t t = t0 + lane;  // the table of this lane in the lane-parallel phases
@@ -1592,16 +1568,6 @@ __global__ __launch_bounds__(TB, 4) void k_slab(SlabArgs a) {
     }
     stamps.mark(4);
     first = false;
-    if (dyn && cidx >= a.nchunks) break;  // (a wave beyond the queue: nothing was its own)
-  }
-  if (dyn && lane == 0) {
-    // the last wave to leave re-arms the queue for the next launch (every other wave has made its last draw before it
-    // counted itself out).  The two words belong to the handle: stepping launches of one handle are ordered on one stream
-    // anyway (they move the same state); ddz_create zeroes them.
-    if (atomicAdd(a.ticket + 1, 1u) == (uint32_t)(nwaves - 1)) {
-      atomicExch(a.ticket, 0u);
-      atomicExch(a.ticket + 1, 0u);
-    }
   }
   stamps.set(5, (unsigned long long)(coop ? 1 : nw));
   stamps.store(coop ? tb0 + wv : tw0, lane == 0 && (coop ? wv < cn : nw > 0));
@@ -1901,8 +1867,9 @@ __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ st
 // ALL legal actions of a state; net.py:99-101 relu(fc1) -> fc2) over the slab lists, with the first layer factorised
 // per (rank, count) by the host glue (doudizhu-rl_amd/dqn_glue.py FactorisedQ.tables):
 //     q[t][j] = b2 + w2 . relu( sum_{r = 0..14} U[r][t][cnt_r(row j of table t)][:] ),   U f32 [15][T][5][256]
-// One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4l..4l+3: a row costs 15
-// coalesced 1-KB reads of the table's own 75 KB of U (L2-resident across its rows), a 4-wide dot and a wave reduction.
+// One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4l..4l+3: the all-zero-count sum
+// once per table (15 coalesced 1-KB reads), then per row two 1-KB reads per rank the action touches (of the table's own
+// 75 KB of U, L2-resident across its rows), a 4-wide dot and a DPP wave reduction.
 // The lists are read where ddz_step_slab left them (counts / rows): no CSR, no padding rows, no host sync.
 constexpr int QH = 256;  // hidden units of fc1 (net.py:147)
 __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, int64_t T, int tpw, const float4* __restrict__ w2,
@@ -1922,25 +1889,33 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
     const float4* ut = U + t * 5 * (QH / 4) + lane;
     const uint4* lrow = rows + t * stride;
     float* qt = q + t * stride;
+    if (n == 0) continue;
+    // h0 = the sum with every count 0 (the pass): once per table; a row then swaps in the terms of the ranks it touches
+    // (an action touches 1.3 ranks on average: 2 reads per touched rank instead of 15 per row)
+    float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 15; ++r) {
+      const float4 v = ut[r * rstride];
+      h0.x += v.x; h0.y += v.y; h0.z += v.z; h0.w += v.w;
+    }
     for (int j0 = 0; j0 < n; j0 += 64) {
       const int m = n - j0 < 64 ? n - j0 : 64;
       uint4 myrow = make_uint4(0, 0, 0, 0);
       if (lane < m) myrow = lrow[j0 + lane];  // one coalesced read of up to 64 rows; row jj is handed round by readlane
+      const uint64_t mynib = pack_row(myrow);
       float res = 0.f;
       for (int jj = 0; jj < m; ++jj) {
-        const uint32_t r0 = rl(myrow.x, jj), r1 = rl(myrow.y, jj), r2 = rl(myrow.z, jj), r3 = rl(myrow.w, jj);
-        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int r = 0; r < 15; ++r) {
-          const uint32_t word = r < 4 ? r0 : r < 8 ? r1 : r < 12 ? r2 : r3;
-          uint32_t c = (word >> (8 * (r & 3))) & 0xFFu;
+        const uint64_t nib = rl64(mynib, jj);  // wave-uniform
+        float4 h = h0;
+        for (uint32_t tm = ge_mask(nib, 1); tm; tm &= tm - 1) {  // the ranks the action touches
+          const int r = __builtin_ctz(tm);
+          uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
           c = c > 4u ? 4u : c;
-          const float4 v = ut[r * rstride + (int64_t)c * (QH / 4)];
-          h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
+          const float4 v = ut[r * rstride + (int64_t)c * (QH / 4)], z = ut[r * rstride];
+          h.x += v.x - z.x; h.y += v.y - z.y; h.z += v.z - z.z; h.w += v.w - z.w;
         }
         float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) p += __shfl_xor(p, d);
+        p = wave_sum_f32(p);
         if (lane == jj) res = p + bias;
       }
       if (lane < m) qt[j0 + lane] = res;  // coalesced
@@ -2290,8 +2265,7 @@ struct ddz_env {
   bool counts_valid;
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
   int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
-  int slab_chunk;     // k_slab: > 0 = tables per chunk of the dynamic chunk queue (large batches), 0 = fixed shares
-  int cus;            // compute units of the device
+  uint32_t auto_next; // next slot of the k_auto2 queue ring
 };
 
 namespace {
@@ -2348,20 +2322,6 @@ int ensure_counts(ddz_env* e, hipStream_t st) {
   return launch_table<F_COUNT, 0>(e, Io{}, st);
 }
 
-// launch geometry of k_slab: fixed shares of tpw tables per wave, or -- large batches -- a resident grid that draws chunks
-// of slab_chunk tables from the handle's queue words (bytes 32..39 of the status block)
-inline dim3 slab_geometry(const ddz_env* e, SlabArgs& a) {
-  a.coop = e->slab_coop;
-  a.ticket = nullptr; a.chunk = 0; a.nchunks = 0;
-  if (e->slab_chunk > 0 && !e->slab_coop) {
-    a.ticket = (uint32_t*)(e->sc.status + 8);
-    a.chunk = e->slab_chunk;
-    a.nchunks = (e->T + a.chunk - 1) / a.chunk;
-    const int64_t want = (a.nchunks + WPB - 1) / WPB, cap = 2 * (int64_t)e->cus;  // two 8-wave blocks per CU are resident
-    return dim3((unsigned)(want < cap ? want : cap));
-  }
-  return dim3((unsigned)e->nblocks);
-}
 }  // namespace
 
 namespace {
@@ -2383,7 +2343,26 @@ static int auto_blocks(int device, int64_t n) {
 // failed / rejected / concurrent launch (another stream of the same handle, the stateless entry point) can leave behind.
 std::atomic<uint32_t> g_ticket_next[MAX_DEVICES];
 uint32_t* g_ticket_base[MAX_DEVICES];  // device address of g_tickets, resolved once per device (under the table mutex)
-constexpr int AUTO_K_SEQUENTIAL = 1, AUTO_K_LANES = 2;
+constexpr int AUTO_K_SEQUENTIAL = 1, AUTO_K_LANES = 2, AUTO_K_LANES_TABLE_ORDER = 3;
+// the handle's form: heaviest hands first (k_auto_order into a slot of the handle's ring), then k_auto2 over that queue
+static int launch_auto_ordered(ddz_env* e, AutoArgs& a, hipStream_t st) {
+  uint8_t* slot_mem = (uint8_t*)e->scratch + e->lay.off_auto + (int64_t)(e->auto_next++ % AUTO_SLOTS) * e->lay.auto_slot_bytes;
+  AutoOrder* slot = (AutoOrder*)slot_mem;
+  int32_t* order = (int32_t*)(slot_mem + 64);
+  static_assert(sizeof(AutoOrder) == 64, "slot header");
+  const hipError_t r = hipMemsetAsync(slot, 0, sizeof(AutoOrder), st);
+  if (r != hipSuccess) return hip_fail(r);
+  const dim3 grid((unsigned)((a.T + AO_BT - 1) / AO_BT)), block(AO_BT);
+  hipLaunchKernelGGL(k_auto_order<0>, grid, block, 0, st, a.state, a.T, a.auto_roles, slot, order, a.ids, a.stats);
+  hipLaunchKernelGGL(k_auto_order<1>, grid, block, 0, st, a.state, a.T, a.auto_roles, slot, order, a.ids, a.stats);
+  int rc = check_launch();
+  if (rc) return rc;
+  a.ticket = &slot->ticket; a.order = order; a.order_hdr = (const uint32_t*)slot;
+  static_assert(offsetof(AutoOrder, total) == 32 && offsetof(AutoOrder, cnt) == 0, "k_auto2 reads words 0, 1 and 8");
+  hipLaunchKernelGGL(k_auto2<true>, dim3((unsigned)auto_blocks(e->device, a.T)), dim3(A2_TB), 0, st, a);
+  return check_launch();
+}
+
 template <bool STATE>
 static int launch_auto(int device, AutoArgs& a, hipStream_t st, int kernel = AUTO_K_LANES) {
   if (kernel == AUTO_K_SEQUENTIAL) {  // the sequential cross-check kernel (ddz_debug_auto_choose_state only)
@@ -2455,17 +2434,6 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
-  {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
-    e->cus = v;
-  }
-  e->slab_chunk = e->tpw >= 8 ? 8 : 0;  // >= 32,768 tables: chunks of 8 from the dynamic queue
-  {
-    DeviceGuard g(device);
-    const hipError_t r = hipMemset(e->sc.status + 8, 0, 8);  // the queue words of k_slab (the kernel re-arms them)
-    if (r != hipSuccess) { free(e); return hip_fail(r); }
-  }
   *out = e;
   return DDZ_OK;
 }
@@ -2553,8 +2521,9 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
+  a.coop = e->slab_coop;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid = slab_geometry(e, a), block(TB);
+  const dim3 grid((unsigned)e->nblocks), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
   do {                                                                                  \
     if (ids) hipLaunchKernelGGL((k_slab<M, true>), grid, block, 0, st, a);              \
@@ -2587,7 +2556,8 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  const dim3 grid = slab_geometry(e, a), block(TB);
+  a.coop = e->slab_coop;
+  const dim3 grid((unsigned)e->nblocks), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
   e->counts_valid = false;
@@ -2819,38 +2789,37 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
   a.status = e->sc.status;
   fill_round_penalty(a);
-  return launch_auto<true>(e->device, a, (hipStream_t)stream);
+  return launch_auto_ordered(e, a, (hipStream_t)stream);
 }
 
 // test hook: ddz_auto_choose_state with an explicit kernel -- 1 = k_auto (sequential walk, wave-uniform control, full
-// enumeration: the cross-check), 2 = k_auto2 (the product kernel).  Same ids by construction; tests compare them.
+// enumeration: the cross-check), 2 = k_auto2 as the product runs it (heaviest hands first), 3 = k_auto2 in table order.
+// Same ids by construction; tests compare them.
 int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!ids || !al(ids, 4) || !al(stats, 8) || auto_roles < 0 || auto_roles > 7) return DDZ_EINVAL;
-  if (kernel != AUTO_K_SEQUENTIAL && kernel != AUTO_K_LANES) return DDZ_EINVAL;
+  if (kernel != AUTO_K_SEQUENTIAL && kernel != AUTO_K_LANES && kernel != AUTO_K_LANES_TABLE_ORDER) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
   a.status = e->sc.status;
   fill_round_penalty(a);
-  return launch_auto<true>(e->device, a, (hipStream_t)stream, kernel);
+  if (kernel == AUTO_K_LANES) return launch_auto_ordered(e, a, (hipStream_t)stream);
+  return launch_auto<true>(e->device, a, (hipStream_t)stream, kernel == AUTO_K_SEQUENTIAL ? AUTO_K_SEQUENTIAL : AUTO_K_LANES);
 }
 
 // test hook: the launch geometry of a handle's table kernels -- tables per wave (1..64, 0 = keep) and whether k_slab runs
 // the one-table-per-wave block-cooperative form (0 / 1, -1 = keep).  Results never depend on either (tests sweep them).
-int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int slab_chunk) {
+int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1 || slab_chunk < -1 || slab_chunk > SLAB_CH)
-    return DDZ_EINVAL;
+  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1) return DDZ_EINVAL;
   if (tables_per_wave > 0) {
     e->tpw = tables_per_wave;
     e->nblocks = (e->T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
     e->counts_valid = false;  // the scan buffers depend on the geometry
-    e->slab_chunk = 0;        // an explicit share per wave means fixed shares (unless slab_chunk asks otherwise below)
   }
   e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
-  if (slab_chunk >= 0) e->slab_chunk = slab_chunk;
   return DDZ_OK;
 }
 

@@ -293,13 +293,13 @@ int ddz_auto_choose(int device_id, const int8_t* hands, const int8_t* lasts, con
 /* test hook: 2 * cards_value (rule_based/utils/evaluator.py:10-47) of every action id, int8[DDZ_NUM_ACTIONS] */
 int ddz_debug_cards_value(int device_id, int8_t* out, void* stream);
 /* test hook: ddz_auto_choose_state with an explicit kernel: 1 = the sequential full-enumeration walk (cross-check),
- * 2 = the lane-parallel branch-and-bound kernel ddz_auto_choose_state always uses.  Same ids by construction.   */
+ * 2 = the lane-parallel branch-and-bound kernel as ddz_auto_choose_state runs it (tables ordered heaviest hand first),
+ * 3 = the same kernel in table order.  Same ids by construction.                                                  */
 int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
 /* test hook: launch geometry of a handle (tables per wavefront 1..64, 0 = keep; block-cooperative one-table-per-wave
- * form of ddz_step_slab 0 / 1, -1 = keep; tables per chunk of ddz_step_slab's dynamic chunk queue 1..16, 0 = fixed
- * shares per wave, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads no
- * environment variables.                                                                                         */
-int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_chunk);
+ * form of ddz_step_slab 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads
+ * no environment variables.                                                                                      */
+int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */

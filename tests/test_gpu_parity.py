@@ -564,7 +564,7 @@ def test_env_view_matches_reference_api(pkg, oracle):
     env.reset(); env.prepare(); ref.reset()
     assert env.get_role_ID() == 2 and env.left.tolist() == [17, 20, 17]        # lord, 1-based
     assert len(env.get_curr_handcards()) == 20
-    assert env.get_last_two_cards() == [[], []]
+    assert env.get_last_two_cards() == [[], []] and env.get_last_outcards().tolist() == []    # a lead: nothing to beat
     face = env.face
     assert face.dtype == torch.float32 and tuple(face.shape) == (6, 15, 4) and face.is_cuda
     acts = env.valid_actions()
@@ -575,6 +575,11 @@ def test_env_view_matches_reference_api(pkg, oracle):
     r, done, _ = env.step_manual(acts[-1])
     assert (r, done) == (0, False) and env.get_role_ID() == 3                  # down moves next
     assert env.taken.sum() == 20 - env.left[1] and env.history[1].sum() == env.taken.sum()
+    # get_last_outcards(): what `down` has to beat = the lord's play as ranks 3..17 (envi.py:103-109; the `last_cards`
+    # of rule_based/utils/utils.py:197)
+    played = env.arr2cards(env.onehot2arr(acts[-1]))
+    assert env.get_last_outcards().tolist() == played.tolist() == env.get_last_two_cards()[0]
+    assert np.array_equal(env.cards2arr(env.get_last_outcards()), env.recent_handout[1])
     with pytest.raises(ValueError):
         env.step_manual(torch.ones((15, 4)))                                    # never legal
     done = False
@@ -1065,14 +1070,12 @@ def test_slab_to_csr_select_step_slab_runs_no_second_enumeration(pkg, oracle):
     assert calls == {"legal": 0, "legal_slab": 1} and env.status() == 0
 
 
-@pytest.mark.parametrize("chunk", [8, 3, 16])
-def test_slab_api_dynamic_chunk_queue_vs_oracle(pkg, oracle, chunk):
-    """k_slab at large batches: waves draw chunks of tables from one queue (first chunk = the wave's own index, the rest
-    by atomic ticket).  70,001 tables -- more chunks than the 4096 resident waves, a ragged last chunk -- x 10 iterations
-    in every mode against the oracle: lists, outputs, full state; and the queue re-arms itself (status, next launch)."""
-    T, seed = 70001, 900 + chunk
+def test_slab_api_all_modes_large_batch_vs_oracle(pkg, oracle):
+    """k_slab at a large batch with the default geometry (70,001 tables: 18 tables per wave = a full chunk of 16 + 2, a
+    ragged last wave) x 10 iterations in every mode against the oracle on ALL tables: lists, outputs, full state."""
+    T, seed = 70001, 908
     rng = np.random.default_rng(seed)
-    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), _debug_slab_chunk=chunk)
+    env = pkg.BatchedEnv(T, seed=seed, device=_dev())
     ref = oracle.OracleEnv(T, seed=seed)
     env.reset(); ref.reset()
     env.rollout_random(23); ref.rollout_random(23)      # desynchronised mid-game states, some games already finished
@@ -1166,15 +1169,12 @@ def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
     assert env.status() == 0
 
 
-@pytest.mark.parametrize("T,chunk", [(777, None), (5000, 1)], ids=["fixed_shares", "dynamic_chunk_queue"])
-def test_stepping_calls_are_graph_capturable(pkg, T, chunk):
+def test_stepping_calls_are_graph_capturable(pkg):
     """Every launch of the stepping API goes to the caller's current stream and nothing in it synchronises, so a caller
     can capture its loop in a hipGraph (torch.cuda.graph) and replay it: 3 replays of 8 captured iterations (observe +
-    select_slab + step_slab, and the fused policy step) == the same 24 iterations issued one by one.  Second case: the
-    dynamic chunk queue of large batches (5000 chunks of one table over 4096 waves: the queue's words are re-armed by
-    the kernel itself, so a replayed launch finds them as the captured one did)."""
-    K = 8
-    a = pkg.BatchedEnv(T, seed=8, device=_dev(), _debug_slab_chunk=chunk)
+    select_slab + step_slab, and the fused policy step) == the same 24 iterations issued one by one."""
+    T, K = 777, 8
+    a = pkg.BatchedEnv(T, seed=8, device=_dev())
     b = pkg.BatchedEnv(T, seed=8, device=_dev())
     a.reset(); b.reset(); a.legal_slab(); b.legal_slab()
     q = torch.rand((T, a.slab_stride), dtype=torch.float32, device=_dev())
