@@ -908,7 +908,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];
       g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
       g_stamps[16 * t + 6] = n_trips; g_stamps[16 * t + 7] = n_lane_trips;
-      for (int k_ = 0; k_ < 5; ++k_) g_stamps[16 * t + 8 + k_] = tsec[k_];
+      for (int k_ = 0; k_ < 2; ++k_) g_stamps[16 * t + 8 + k_] = tsec[k_];
+      g_stamps[16 * t + 10] = (unsigned long long)(blockIdx.x * A2_WPB + wv);  // which wave decided it, when (timeline)
+      g_stamps[16 * t + 11] = tq[0]; g_stamps[16 * t + 12] = tq[3];
       g_stamps[16 * t + 13] = tq_enum - tq[0]; g_stamps[16 * t + 14] = tq_sort - tq_enum; g_stamps[16 * t + 15] = tq_bounds - tq_sort;
     }
 #endif

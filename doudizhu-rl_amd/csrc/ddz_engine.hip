@@ -69,10 +69,10 @@ inline Layout make_layout(int64_t T) {
   l.off_local = o;      o = align_up(o + 2 * T * 4, 256);
   l.off_blk_tot = o;    o = align_up(o + 2 * l.nblk * 4, 256);
   l.off_blk_stats = o;  o = align_up(o + T * 32, 256);           // one slot per wave (<= T)
-  l.off_status = o;     o = align_up(o + 64, 256);
   l.auto_slot_bytes = align_up(64 + 4 * T, 256);                  // AutoOrder header + order[T]
   l.off_auto = o;       o = align_up(o + AUTO_SLOTS * l.auto_slot_bytes, 256);
-  l.bytes = o;
+  l.off_status = o;     o = align_up(o + 64, 256);               // (the last 256 bytes: callers of the stateless entry
+  l.bytes = o;                                                    //  points read the status word at bytes - 256)
   return l;
 }
 struct Scratch {  // device pointers into the scratch buffer
@@ -353,7 +353,8 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
     if (mains) {
       const int lo = __builtin_ctz(mains), hi = 31 - __builtin_clz(mains);
       if (LEAD || f.lc == THREE_ONE) scan(ID_THREE_ONE + 14 * lo, 14 * (hi - lo + 1));
-      if (LEAD || f.lc == THREE_TWO) scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
+      if ((LEAD || f.lc == THREE_TWO) && __builtin_popcount(m2) >= 2)  // (a pair of another rank exists at all)
+        scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
     }
   }
   if (LEAD) {  // chains (card.py:86-105): the three categories are contiguous ids
@@ -392,6 +393,9 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
       const int maxL = runlen < hi ? runlen : hi;
       for (int L = 2; L <= maxL && s + L <= 12; ++L) {
         if (!(LEAD || (L == f.ll && s > f.lv))) continue;
+        // L kickers of distinct ranks outside the run (card.py:110-129): without L such ranks in the hand the whole id
+        // block (55-330 ids, 1-6 rounds) holds no legal move
+        if (__builtin_popcount((mult == 1 ? m1 : m2) & ~(((1u << L) - 1u) << s)) < L) continue;
         const int idb = idb0 + before + (L > 2 ? sz2 : 0) + (L > 3 ? sz3 : 0) + (L > 4 ? sz4 : 0);
         const int size = L == 2 ? sz2 : L == 3 ? sz3 : L == 4 ? sz4 : 252;
         const int list = L == 2 ? list2 : L == 3 ? list3 : L == 4 ? list4 : list5;
@@ -412,6 +416,7 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
   if (LEAD || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
     for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
       const int q = __builtin_ctz(qm);
+      if (__builtin_popcount(m2 & ~(1u << q)) < 2) continue;  // two pairs of other ranks, or the 66-id block is empty
       n = scan_combos<EM, IDS>(2, 66, ID_FOUR_TAKE_TWO + 66 * q, 4ull << (4 * q), q, 1, 2, FOUR_TAKE_TWO, hot, hand8,
                                lane, o, n, pk);
     }

@@ -39,7 +39,8 @@ class _Pending:
         return self._out
 
 
-def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=None, compact=False):
+def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=None, compact=False,
+                        _force_collective=False):
     """traj: uint8 [n_iters, T_local, 32] of this rank -> uint8 [n_iters, T_total, 32], tables in
     global id order, on every rank (dst=None: all_gather) or only on rank `dst` (gather to the
     learner; the other ranks get None).  One collective per call (few, large messages: xGMI is
@@ -56,7 +57,8 @@ def gather_trajectories(traj, group=None, dst=None, async_op=False, shard_sizes=
         from .engine import pack_trajectory
         traj = pack_trajectory(traj)
     rec = traj.shape[2]
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    # (_force_collective: tests run the real collective on a one-rank group -- RCCL on a single-GPU box)
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collective):
         pend = _Pending([], lambda: traj)
         return pend if async_op else pend.result()
     world, rank = dist.get_world_size(group), dist.get_rank(group)

@@ -172,7 +172,8 @@ int ddz_rows_to_onehot(int device_id, const int8_t* rows, int64_t n, float* out,
 /* Replaces r.get_moves(hand15, last15) (envi.py:111, server/core.py:65, server/CFR.py:55)
  * for n independent queries: hands/lasts int8[n][16] (byte 15 ignored; `last` all-zero =
  * lead; a `last` that is no combo of the action space yields an empty list and status
- * bit 2).  scratch: ddz_scratch_bytes(n) bytes.                                        */
+ * bit 2).  scratch: ddz_scratch_bytes(n) bytes, zero-filled by the caller; its status
+ * word (bits as ddz_status) is the int32 at byte ddz_scratch_bytes(n) - 256.           */
 int ddz_get_moves(int device_id, const int8_t* hands, const int8_t* lasts, int64_t n,
                   int32_t* offsets, int8_t* rows, int32_t* ids, int64_t row_capacity,
                   void* scratch, int64_t scratch_bytes, void* stream);

@@ -993,6 +993,54 @@ def test_bench_two_ranks_rehearsal_gathers_the_union(pkg):
     assert digest == ex["digest"]
 
 
+def test_rccl_collectives_of_the_exchange_on_one_rank(pkg):
+    """The end-of-batch exchange through the REAL backend: a one-rank `nccl` (= RCCL) process group on this GPU, created
+    the way bench.py creates it (init_process_group("nccl", device_id=...)), runs the exact collectives of
+    dist.gather_trajectories -- gather of uint8 records to the learner rank (asynchronous, two batches in flight),
+    all_gather_into_tensor, the size exchange, barrier, all_reduce of the timing scalars -- and returns the records
+    unchanged.  (Several ranks need several GPUs: the driver's SCALE run; world-2 semantics are covered on gloo.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = r"""
+import datetime, importlib, os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+pkg = importlib.import_module("doudizhu-rl_amd"); ddist = importlib.import_module("doudizhu-rl_amd.dist")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(minutes=2))
+T, K = 3000, 12
+env = pkg.BatchedEnv(T, seed=3, device=dev, want_ids=False); env.reset()
+traj = torch.zeros((K, T, 32), dtype=torch.uint8, device=dev)
+env.rollout_random(K, traj=traj)
+packed = pkg.pack_trajectory(traj)
+dist.barrier(); torch.cuda.synchronize(dev)
+h1 = ddist.gather_trajectories(packed[: K // 2].contiguous(), dst=0, async_op=True, shard_sizes=[T], _force_collective=True)
+h2 = ddist.gather_trajectories(packed[K // 2:].contiguous(), dst=0, async_op=True, shard_sizes=[T], _force_collective=True)
+got = torch.cat([h1.result(), h2.result()])
+assert torch.equal(got, packed)
+full = ddist.gather_trajectories(traj, _force_collective=True)              # all_gather + size exchange, 32-byte records
+assert torch.equal(full, traj)
+comp = ddist.gather_trajectories(traj, dst=0, compact=True, _force_collective=True)
+assert torch.equal(comp, packed)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.5
+rec = ddist.unpack_trajectory(got[-1])
+assert int(rec["role"].max()) <= 2 and int(rec["id"][rec["flags"] == 0].max()) < 13527
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", dist.Backend.NCCL)
+""" % repo
+    env_ = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env_.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env_)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+
+
 def test_slab_to_csr_equals_legal(pkg):
     """ddz_slab_to_csr: the slab lists packed to CSR are byte-identical to ddz_legal's offsets / rows / ids on the same
     states (ragged sizes, mid-game and fresh deals, a table count that is not a multiple of the block), a choice index

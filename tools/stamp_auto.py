@@ -47,9 +47,31 @@ tot = s[:, :3].sum(1)
 print(f"  total              mean {tot.mean():9.0f}  p99 {np.percentile(tot, 99):9.0f}  max {tot.max():9.0f}   sum/1024 waves {tot.sum() / 1024:.0f}")
 print(f"  frontier items mean {s[:, 3].mean():.0f} max {s[:, 3].max():.0f}; nodes mean {s[:, 4].mean():.0f} max {s[:, 4].max():.0f}; candidates mean {s[:, 5].mean():.0f} max {s[:, 5].max():.0f}")
 print(f"  search loop: trips mean {s[:, 6].mean():.0f} max {s[:, 6].max():.0f}; cycles per trip {s[:, 2].sum() / s[:, 6].sum():.0f}; active lanes per trip {s[:, 7].sum() / s[:, 6].sum():.1f}")
-names = ["take items / donations", "step (scan, descend)", "score", "open node", "backtrack"]
+names = ["take items / donations", "step (scan, descend)"]
 for k, nm in enumerate(names):
     print(f"    per trip: {nm:24s} {s[:, 8 + k].sum() / s[:, 6].sum():7.0f} cycles")
+# timeline: who decided what when (s_memtime is one clock for the whole chip)
+wave, t_start, t_end = s[:, 10].astype(np.int64), s[:, 11], s[:, 12]
+t0 = t_start.min()
+span = t_end.max() - t0
+nw = int(wave.max()) + 1
+last_end = np.zeros(nw); first_start = np.full(nw, np.inf); busy = np.zeros(nw); ndec = np.zeros(nw)
+for w, a_, b_ in zip(wave, t_start, t_end):
+    last_end[w] = max(last_end[w], b_ - t0); first_start[w] = min(first_start[w], a_ - t0); busy[w] += b_ - a_; ndec[w] += 1
+print(f"  timeline: span {span:.0f} cycles over {nw} waves; per wave: decisions {ndec.mean():.1f}, busy {busy.mean():.0f} "
+      f"({busy.mean() / span:.0%} of the span), first start {first_start.mean():.0f}, last end mean {last_end.mean():.0f} min {last_end.min():.0f}")
+order_ = np.argsort(t_start)
+dur = (t_end - t_start)[order_]
+q = len(dur) // 10
+print("  mean decision cycles by start-time decile:", [int(dur[i * q:(i + 1) * q].mean()) for i in range(10)])
+heavy = np.argsort(-(t_end - t_start))[:5]
+print("  heaviest decisions: (start, duration) =", [(int(t_start[h] - t0), int(t_end[h] - t_start[h])) for h in heavy])
+gaps = []
+for w in range(0, nw, 37):
+    idx = np.nonzero(wave == w)[0]
+    idx = idx[np.argsort(t_start[idx])]
+    gaps += list(t_start[idx][1:] - t_end[idx][:-1])
+print(f"  gap between a wave's decisions (ticket + order + state loads): mean {np.mean(gaps):.0f} p90 {np.percentile(gaps, 90):.0f} cycles")
 heavy = np.argsort(-tot)[:5]
 for h in heavy:
     print("   heavy:", [int(x) for x in s[h, :8]])
