@@ -1151,6 +1151,7 @@ struct SlabArgs {
   float4* face;         // [T][P][15] `face` of the NEW states, or null
   int face_variant;
   int coop;             // tpw == 1: wave 0 of a block runs the lane-parallel phases of the block's tables
+  int lpt;              // tpw >= 2: deals + lists of a block's tables go through a block work list, most expensive first
 };
 constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
 
@@ -1306,10 +1307,31 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   // for the unluckiest wave, whose 16 lists cost 1.76 x the mean -- was built and measured in round 3: 112-245 us instead
   // of 34 us.  Thousands of device-scope atomics on ONE address serialise at ~18 ns each on this multi-XCD part
   // (profiles/r03_notes.md); fixed shares it is.)
+  // Block work list (a.lpt; every mode but the fused policy step).  A table whose game just ended costs its wave a deal
+  // (~3-5 k cycles) and the lord's 20-card lead list (~8-10 k) where an ordinary table costs 2 k; a wave whose 16 tables held
+  // three finished games took 82 k cycles against a mean of 46 k, and the launch lasts as long as its slowest wave
+  // (tools/launch_floor_probe.hip: a launch of this shape whose waves all take N cycles lasts N cycles + 2.5 us).  So the
+  // waves of a block publish their tables' pending work in LDS -- (hand, combo to beat, table), or (episode, table) for a
+  // game to deal -- bucketed by an estimate of its cost, and then take the items one by one, MOST EXPENSIVE FIRST, with an
+  // LDS ticket: the block ends with its cheapest lists (a follow of a single / pair / triple: ~0.5 k cycles), whoever owned
+  // the tables.  (Round 2 tried the lists alone in table order, this round the lists alone most expensive first: no gain --
+  // the deals stayed with the owner wave in front of a block barrier; profiles/r03_notes.md.)
+  constexpr int WL_CLASSES = 4;
+  __shared__ uint4 s_work[WL_CLASSES][WPB * SLAB_CH];
+  __shared__ int s_wcnt[WL_CLASSES + 1];  // [4] = the ticket
+  const bool lpt = a.lpt != 0 && !coop && MODE != STEP_Q;
+  const int64_t tblk0 = (int64_t)blockIdx.x * WPB * a.tpw;  // first table of this block
   bool first = true;
-  for (int c0 = 0; first || c0 < nw; c0 += SLAB_CH) {  // every wave passes the block barrier of the first chunk
+  // (with the work list every wave of a block runs the same number of rounds: the rounds contain block barriers)
+  for (int c0 = 0; first || (lpt ? c0 < a.tpw : c0 < nw); c0 += SLAB_CH) {  // every wave passes the barrier of the first chunk
     const int64_t t0 = tw0 + c0;
-    const int ntab = nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
+    const int ntab = nw - c0 <= 0 ? 0 : nw - c0 < SLAB_CH ? nw - c0 : SLAB_CH;  // 0 for a wave without tables
+    if (lpt) {
+      if (!first) __syncthreads();  // the previous round's items are all taken
+      if (threadIdx.x <= WL_CLASSES) s_wcnt[threadIdx.x] = 0;
+    }
+    bool deal_l = false;  // this lane's table ended and is dealt by whoever takes its work item ...
+    uint32_t deal_ep = 0;  // ... as episode deal_ep
     const int nrows = ntab * DDZ_NFIELDS;
     const bool valid = lane < ntab;
     const int64_t t = t0 + lane;  // the table of this lane in the lane-parallel phases
@@ -1510,6 +1532,10 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       }
       // finished games with auto-reset: the next episode's deal (wave-wide), the lord leads
       uint64_t wr = a.auto_reset ? wm : 0ull;
+      const uint64_t deferred = lpt ? wr : 0ull;  // (work list: dealt in the list phase, by any wave of the block)
+      deal_l = (deferred >> lane) & 1ull;
+      deal_ep = episode + 1u;
+      if (lpt) wr = 0ull;
       while (wr) {
         const int i = __builtin_ctzll(wr);
         wr &= wr - 1;
@@ -1524,14 +1550,30 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       // the rows of the tables that moved, back to the state: coalesced 16-byte stores
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (lane < nrows && ((chm >> (lane / DDZ_NFIELDS)) & 1)) sp[lane] = srow[lane];
-      if (64 + lane < nrows && ((chm >> ((64 + lane) / DDZ_NFIELDS)) & 1)) sp[64 + lane] = srow[64 + lane];
-      if (128 + lane < nrows && ((chm >> ((128 + lane) / DDZ_NFIELDS)) & 1)) sp[128 + lane] = srow[128 + lane];
+      const uint64_t stm = chm & ~deferred;  // (a deferred deal writes its table's rows itself)
+      if (lane < nrows && ((stm >> (lane / DDZ_NFIELDS)) & 1)) sp[lane] = srow[lane];
+      if (64 + lane < nrows && ((stm >> ((64 + lane) / DDZ_NFIELDS)) & 1)) sp[64 + lane] = srow[64 + lane];
+      if (128 + lane < nrows && ((stm >> ((128 + lane) / DDZ_NFIELDS)) & 1)) sp[128 + lane] = srow[128 + lane];
     }
     if (coop && valid) s_share[lane] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, live ? 1u : 0u);
     }  // ntab > 0
     stamps.mark(3);
-    if (first) __syncthreads();  // the hot records are in LDS
+    if (first || lpt) __syncthreads();  // the hot records are in LDS (and the work list's counters are zero)
+    if (lpt) {
+      // publish: lane i = table t0 + i.  Cost classes: 0 a game to deal (+ the lord's 20-card lead) or a lead from a hand
+      // with two triples / a bomb (planes, four-with-two: many kicker rounds), 1 any other lead, 2 a follow of a chain /
+      // plane / ..., 3 a follow of a single / pair / triple
+      if (live) {
+        const int lc = (int)(qinfo & 0xFF);
+        const bool lead = lc == EMPTY;
+        const bool rich = __builtin_popcount(ge_mask(qhand, 3)) >= 2 || ge_mask(qhand, 4) != 0;
+        const int cls = deal_l ? 0 : lead ? (rich ? 0 : 1) : lc <= TRIPLE ? 3 : 2;
+        const int pos = atomicAdd(&s_wcnt[cls], 1);
+        s_work[cls][pos] = deal_l ? make_uint4(deal_ep, 0u, LEAD, (uint32_t)(t - tblk0) | 0x80000000u)
+                                  : make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, (uint32_t)(t - tblk0));
+      }
+      __syncthreads();
+    }
     if (MODE == STEP_Q && a.face && face_first && ntab > 0) {
       face_phase(srow, ntab, lane, a.face, a.face_variant, t0);
       stamps.mark(6);
@@ -1548,7 +1590,34 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
         s_rows += n;
       }
     }
-    uint64_t lv = coop ? 0ull : __ballot(live);
+    if (lpt) {
+      const int n0 = s_wcnt[0], n1 = n0 + s_wcnt[1], n2 = n1 + s_wcnt[2], n3 = n2 + s_wcnt[3];
+      for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&s_wcnt[WL_CLASSES], 1);
+        k = (int)rfl((uint32_t)k);
+        if (k >= n3) break;
+        const int cls = k < n0 ? 0 : k < n1 ? 1 : k < n2 ? 2 : 3;
+        const uint4 e = s_work[cls][k - (cls == 0 ? 0 : cls == 1 ? n0 : cls == 2 ? n1 : n2)];
+        const uint32_t ew = rfl(e.w);
+        const int64_t tt = tblk0 + (int64_t)(ew & 0x7FFFFFFFu);
+        uint64_t hand = (uint64_t)rfl(e.x) | ((uint64_t)rfl(e.y) << 32);
+        if (ew >> 31) {  // a finished game: the next episode's deal (native prepare(), spec v2), the lord leads
+          const uint32_t ep = rfl(e.x);
+          uint64_t h0, h1, h2;
+          deal_wave(a.gid_base + (uint64_t)tt, ep, a.k0, a.k1, lane, h0, h1, h2);
+          if (lane < DDZ_NFIELDS)
+            ((uint4*)(a.state + tt * STATE_ROW_BYTES))[lane] =
+                lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+                : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, ep, 0) : make_uint4(0, 0, 0, 0);
+          hand = h1;
+        }
+        const int n = slab_list<IDS>(hand, rfl(e.z), tt * a.stride, a.stride, a.rows, a.ids, hot, lane, fl, a.status);
+        if (lane == 0) a.counts[tt] = n;
+        s_rows += n;
+      }
+    }
+    uint64_t lv = (coop || lpt) ? 0ull : __ballot(live);
     while (lv) {
       const int i = __builtin_ctzll(lv);
       lv &= lv - 1;
@@ -1566,7 +1635,8 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       stamps.mark(6);
     }
     if (valid) {  // the per-table outputs: consecutive addresses, one store each
-      if (!coop) a.counts[t] = n_l;
+      if (lpt) { if (!live) a.counts[t] = 0; }  // (a live table's size is written by the wave that took its item)
+      else if (!coop) a.counts[t] = n_l;
       if (a.done) a.done[t] = (uint8_t)o_done;
       if (a.reward) a.reward[t] = (int8_t)o_reward;
       if (a.illegal) a.illegal[t] = (uint8_t)o_illegal;
@@ -1576,7 +1646,7 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   }
   stamps.set(5, (unsigned long long)(coop ? 1 : nw));
   stamps.store(coop ? tb0 + wv : tw0, lane == 0 && (coop ? wv < cn : nw > 0));
-  if ((coop ? wv < cn : nw > 0) && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
+  if ((coop ? wv < cn : (nw > 0 || lpt)) && lane == 0) {  // each wave owns its statistics slot (as in k_rollout)
     int64_t* ws = a.wave_stats + 4 * wave;
     ws[0] += s_ply; ws[1] += s_eps; ws[2] += (int64_t)s_lord | ((int64_t)s_up << 32); ws[3] += s_rows;
   }
@@ -2271,6 +2341,7 @@ struct ddz_env {
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
   int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
   uint32_t auto_next; // next slot of the k_auto2 queue ring
+  int slab_lpt;       // k_slab: block work list of deals + lists, heaviest first (tpw >= 2)
 };
 
 namespace {
@@ -2439,6 +2510,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->nblocks = (T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
+  e->slab_lpt = e->tpw >= 2;
   *out = e;
   return DDZ_OK;
 }
@@ -2526,7 +2598,7 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
-  a.coop = e->slab_coop;
+  a.coop = e->slab_coop; a.lpt = e->slab_lpt;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)e->nblocks), block(TB);
 #define DDZ_LAUNCH_SLAB(M)                                                              \
@@ -2561,7 +2633,7 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  a.coop = e->slab_coop;
+  a.coop = e->slab_coop; a.lpt = 0;
   const dim3 grid((unsigned)e->nblocks), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
@@ -2816,15 +2888,18 @@ int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_
 
 // test hook: the launch geometry of a handle's table kernels -- tables per wave (1..64, 0 = keep) and whether k_slab runs
 // the one-table-per-wave block-cooperative form (0 / 1, -1 = keep).  Results never depend on either (tests sweep them).
-int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop) {
+int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int slab_work_list) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1) return DDZ_EINVAL;
+  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1 || slab_work_list < -1 || slab_work_list > 1)
+    return DDZ_EINVAL;
   if (tables_per_wave > 0) {
     e->tpw = tables_per_wave;
     e->nblocks = (e->T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
     e->counts_valid = false;  // the scan buffers depend on the geometry
+    e->slab_lpt = e->tpw >= 2;
   }
   e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
+  if (slab_work_list >= 0) e->slab_lpt = slab_work_list && e->tpw >= 2;
   return DDZ_OK;
 }
 

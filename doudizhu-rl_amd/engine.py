@@ -46,7 +46,8 @@ class BatchedEnv:
     """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
-                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None):
+                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None,
+                 _debug_slab_work_list=None):
         # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
         # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
         self.native_joker_kickers = bool(native_joker_kickers)
@@ -79,10 +80,11 @@ class BatchedEnv:
                                   _p(self.state), self.state.numel(), _p(self.scratch),
                                   self.scratch.numel()))
         self._h = h
-        if _debug_tables_per_wave is not None or _debug_slab_coop is not None:
+        if _debug_tables_per_wave is not None or _debug_slab_coop is not None or _debug_slab_work_list is not None:
             # test hook: results never depend on the launch geometry
             check(self.lib.ddz_debug_set_geometry(h, int(_debug_tables_per_wave or 0),
-                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop))))
+                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop)),
+                                                  -1 if _debug_slab_work_list is None else int(bool(_debug_slab_work_list))))
 
     def close(self):
         if getattr(self, "_h", None):

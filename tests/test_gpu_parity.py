@@ -1164,14 +1164,16 @@ def test_slab_api_all_modes_large_batch_vs_oracle(pkg, oracle):
     assert env.status() == 0
 
 
-@pytest.mark.parametrize("tpw", [1, 5, 16, 23, 40])
+@pytest.mark.parametrize("tpw", [1, 5, 16, 23, 40, -16])
 def test_slab_api_chunks_and_modes_vs_oracle(pkg, oracle, tpw):
     """k_slab handles a wave's tables in lane-parallel chunks of 16: every chunking (one table per wave, a partial chunk,
     exactly one, 16 + 7, 16 + 16 + 8; the last wave ragged) x every mode (CHOICE, ROWS, IDS with engine draws, RANDOM)
     against the oracle: lists, done / r / illegal, trajectory records and the full state after every iteration."""
+    work_list = tpw > 0       # (-16: 16 tables per wave WITHOUT the block work list of deals + lists: every wave its own)
+    tpw = abs(tpw)
     T, seed = 1003, 40 + tpw
     rng = np.random.default_rng(seed)
-    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), _debug_tables_per_wave=tpw)  # ddz_debug_set_geometry
+    env = pkg.BatchedEnv(T, seed=seed, device=_dev(), _debug_tables_per_wave=tpw, _debug_slab_work_list=work_list)  # ddz_debug_set_geometry
     ref = oracle.OracleEnv(T, seed=seed)
     env.reset(); ref.reset()
     counts, rows, ids = env.legal_slab()
