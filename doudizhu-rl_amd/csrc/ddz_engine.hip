@@ -334,6 +334,11 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
 // superset -- and cheap.
 template <int EM, bool IDS, bool LEAD, class HT>
 __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const HT& hot, int lane, const Out& o, Pick& pk) {
+  // PRUNE: skip kicker blocks / ranges that cannot hold a legal move (fewer kicker ranks in the hand than kickers needed).
+  // Measured A/B (profiles/r03_notes.md): -16 % on lists of plane-rich hands (the stress leg, the tail of k_slab), but +3 %
+  // on k_rollout's step, where such hands are rare and the extra scalar work sits on every lead: off for the staging
+  // emission of the rollout kernel, on everywhere else.
+  constexpr bool PRUNE = EM != EM_STAGE;
   const uint64_t hand8 = hand | 0x8888888888888888ull;
   const int cnt = lane < 15 ? (int)((hand >> (4 * (lane & 15))) & 15) : 0;
   const uint32_t m1 = (uint32_t)__ballot(cnt >= 1) & M15;
@@ -353,7 +358,7 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
     if (mains) {
       const int lo = __builtin_ctz(mains), hi = 31 - __builtin_clz(mains);
       if (LEAD || f.lc == THREE_ONE) scan(ID_THREE_ONE + 14 * lo, 14 * (hi - lo + 1));
-      if ((LEAD || f.lc == THREE_TWO) && __builtin_popcount(m2) >= 2)  // (a pair of another rank exists at all)
+      if ((LEAD || f.lc == THREE_TWO) && (!PRUNE || __builtin_popcount(m2) >= 2))  // (a pair of another rank exists at all)
         scan(ID_THREE_TWO + 12 * lo, 12 * (hi - lo + 1));
     }
   }
@@ -395,7 +400,7 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
         if (!(LEAD || (L == f.ll && s > f.lv))) continue;
         // L kickers of distinct ranks outside the run (card.py:110-129): without L such ranks in the hand the whole id
         // block (55-330 ids, 1-6 rounds) holds no legal move
-        if (__builtin_popcount((mult == 1 ? m1 : m2) & ~(((1u << L) - 1u) << s)) < L) continue;
+        if (PRUNE && __builtin_popcount((mult == 1 ? m1 : m2) & ~(((1u << L) - 1u) << s)) < L) continue;
         const int idb = idb0 + before + (L > 2 ? sz2 : 0) + (L > 3 ? sz3 : 0) + (L > 4 ? sz4 : 0);
         const int size = L == 2 ? sz2 : L == 3 ? sz3 : L == 4 ? sz4 : 252;
         const int list = L == 2 ? list2 : L == 3 ? list3 : L == 4 ? list4 : list5;
@@ -416,7 +421,7 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
   if (LEAD || f.lc == FOUR_TAKE_TWO)                // card.py:148-153
     for (uint32_t qm = m4 & above; qm; qm &= qm - 1) {
       const int q = __builtin_ctz(qm);
-      if (__builtin_popcount(m2 & ~(1u << q)) < 2) continue;  // two pairs of other ranks, or the 66-id block is empty
+      if (PRUNE && __builtin_popcount(m2 & ~(1u << q)) < 2) continue;  // two pairs of other ranks, or the 66-id block is empty
       n = scan_combos<EM, IDS>(2, 66, ID_FOUR_TAKE_TWO + 66 * q, 4ull << (4 * q), q, 1, 2, FOUR_TAKE_TWO, hot, hand8,
                                lane, o, n, pk);
     }
@@ -1307,7 +1312,7 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   // for the unluckiest wave, whose 16 lists cost 1.76 x the mean -- was built and measured in round 3: 112-245 us instead
   // of 34 us.  Thousands of device-scope atomics on ONE address serialise at ~18 ns each on this multi-XCD part
   // (profiles/r03_notes.md); fixed shares it is.)
-  // Block work list (a.lpt; every mode but the fused policy step).  A table whose game just ended costs its wave a deal
+  // Block work list (a.lpt; every mode but the fused policy step WITH a face output).  A table whose game just ended costs its wave a deal
   // (~3-5 k cycles) and the lord's 20-card lead list (~8-10 k) where an ordinary table costs 2 k; a wave whose 16 tables held
   // three finished games took 82 k cycles against a mean of 46 k, and the launch lasts as long as its slowest wave
   // (tools/launch_floor_probe.hip: a launch of this shape whose waves all take N cycles lasts N cycles + 2.5 us).  So the
@@ -1319,7 +1324,9 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   constexpr int WL_CLASSES = 4;
   __shared__ uint4 s_work[WL_CLASSES][WPB * SLAB_CH];
   __shared__ int s_wcnt[WL_CLASSES + 1];  // [4] = the ticket
-  const bool lpt = a.lpt != 0 && !coop && MODE != STEP_Q;
+  const bool lpt = a.lpt != 0 && !coop && !(MODE == STEP_Q && a.face);  // (with `face` the owner wave's face phase needs the
+                                                                         //  dealt rows, and the launch is bound by its 94 MB of
+                                                                         //  face stores: measured 48.1 -> 48.8 us with the list)
   const int64_t tblk0 = (int64_t)blockIdx.x * WPB * a.tpw;  // first table of this block
   bool first = true;
   // (with the work list every wave of a block runs the same number of rounds: the rounds contain block barriers)
@@ -2633,7 +2640,7 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  a.coop = e->slab_coop; a.lpt = 0;
+  a.coop = e->slab_coop; a.lpt = e->slab_lpt;
   const dim3 grid((unsigned)e->nblocks), block(TB);
   if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);

@@ -448,13 +448,18 @@ def test_policy_step_slab_equals_separate_calls(pkg, eps, variant, want_ids, tpw
         ta = torch.zeros((T, 32), dtype=torch.uint8, device=_dev())
         tb = torch.zeros((T, 32), dtype=torch.uint8, device=_dev())
         ca = torch.empty(T, dtype=torch.int32, device=_dev())
-        da, ra, ia, fa = a.policy_step_slab(q, eps, face_variant=variant, choice_out=ca, auto_reset=auto, traj=ta)
+        with_face = it % 4 != 3   # every fourth iteration without a face output: that form of the fused launch hands
+        da, ra, ia, fa = a.policy_step_slab(q, eps, face_variant=variant if with_face else None, choice_out=ca,   # deals and
+                                            auto_reset=auto, traj=ta)                             # lists out by the block work list
         cb = b.select_slab(q, eps)
         db, rb, ib = b.step_slab(cb, pkg.STEP_CHOICE, auto_reset=auto, traj=tb)
         fb = b.observe(variant)
         assert torch.equal(ca, cb) and torch.equal(da, db) and torch.equal(ra, rb) and torch.equal(ia, ib), it
         assert torch.equal(ta, tb) and torch.equal(a.state, b.state) and torch.equal(a.counts, b.counts), it
-        assert fa.shape == (T, P, 15, 4) and torch.equal(fa.view(torch.int32), fb.view(torch.int32)), it
+        if with_face:
+            assert fa.shape == (T, P, 15, 4) and torch.equal(fa.view(torch.int32), fb.view(torch.int32)), it
+        else:
+            assert fa is None
         m = torch.arange(a.slab_stride, device=_dev())[None, :] < a.counts[:, None]
         assert torch.equal(a.slab_rows()[m], b.slab_rows()[m])
         if want_ids:

@@ -100,6 +100,55 @@ if c or st:
 copy("auto/stats/p_kernel_stats.csv", "r03_config4_kernel_stats.csv")
 for f in ("config4_random_65536.txt", "config4_net_65536.txt", "config4_random_4096.txt"):
     copy("auto/" + f, "r03_" + f)
+# ---- rollout: HBM counters + instruction counters of k_rollout -> pmc_traffic.json (what bench.py reads)
+def rollout_counters(d):
+    path = os.path.join(G, d, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        return None, None
+    disp = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        if "k_rollout" in r["Kernel_Name"]:
+            disp[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    big = max(disp, key=lambda k: max(disp[k].values()))  # the long launch
+    trace = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+             for r in csv.DictReader(open(os.path.join(G, d, "p_kernel_trace.csv")))}
+    return dict(disp[big]), trace[big]
+
+
+fetch, _ = rollout_counters("rollout/pmc_FETCH_SIZE")
+write, _ = rollout_counters("rollout/pmc_WRITE_SIZE")
+mix, ns = rollout_counters("rollout/pmc_mix")
+if fetch and write and mix:
+    old = json.load(open(os.path.join(P, "pmc_traffic.json")))
+    steps, steps_mix = 4096 * 2000, 4096 * 20000
+    fk, wk = fetch["FETCH_SIZE"], write["WRITE_SIZE"]
+    out = {"k_rollout": {
+        "hbm_bytes_per_env_step": (2 * fk + wk) * 1024 / steps,
+        "fetch_bytes_per_env_step": 2 * fk * 1024 / steps, "write_bytes_per_env_step": wk * 1024 / steps,
+        "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "env_steps": steps,
+        "workload": "tools/run_rollout.py 4096 2000 (4096 tables, 2000 in-launch iterations, seed 0), round-3 kernel",
+        "method": "tools/profile.sh rollout: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
+                  "bytes = KB*1024, FETCH doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
+                  "WRITE_SIZE taken as is (16-B-per-lane stores).  Every iteration overwrites the same state rows / list slab "
+                  "of its table, so the write-back L2 merges them: HBM sees far fewer bytes than the kernel stores",
+        "valu": {
+            "SQ_INSTS_VALU_per_env_step": mix["SQ_INSTS_VALU"] / steps_mix,
+            "SQ_INSTS_SALU_per_env_step": mix["SQ_INSTS_SALU"] / steps_mix,
+            "SQ_INSTS_BRANCH_per_env_step": mix["SQ_INSTS_BRANCH"] / steps_mix,
+            "SQ_INSTS_LDS_per_env_step": mix["SQ_INSTS_LDS"] / steps_mix,
+            "SQ_WAIT_ANY_share_of_wave_cycles": mix["SQ_WAIT_ANY"] / mix["SQ_WAVE_CYCLES"],
+            "GRBM_GUI_ACTIVE": mix["GRBM_GUI_ACTIVE"], "xcds": 8, "launch_ns": ns,
+            "clock_GHz": mix["GRBM_GUI_ACTIVE"] / 8 / ns,
+            "env_steps_per_s_in_this_launch": steps_mix / (ns * 1e-9),
+            "workload": "tools/run_rollout.py 4096 20000 (one launch, 81.92 M env steps), round-3 kernel"},
+        "valu_mix": old["k_rollout"].get("valu_mix")}}
+    json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    v = out["k_rollout"]["valu"]
+    print("k_rollout per step: VALU %.1f SALU %.1f branch %.1f LDS %.1f; clock %.3f GHz; %.4g steps/s; HBM %.2f B/step; waiting %.0f %%" % (
+        v["SQ_INSTS_VALU_per_env_step"], v["SQ_INSTS_SALU_per_env_step"], v["SQ_INSTS_BRANCH_per_env_step"],
+        v["SQ_INSTS_LDS_per_env_step"], v["clock_GHz"], v["env_steps_per_s_in_this_launch"],
+        out["k_rollout"]["hbm_bytes_per_env_step"], 100 * v["SQ_WAIT_ANY_share_of_wave_cycles"]))
+
 # ---- bench / dqn / probe / stamps
 copy("bench/bench.json", "r03_bench.json")
 copy("bench/bench_stats/p_kernel_stats.csv", "r03_bench_kernel_stats.csv")
