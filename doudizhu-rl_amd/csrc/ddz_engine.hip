@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
 // A[cnt][k][c] = the action plane's thermometer (envi.py:139-146: slots < cnt set) through conv_k.  One block of 256
 // threads = the 256 channels; a thread keeps its channel's weights in registers (P * 10 + 4 + 16 floats) and walks over
 // (table, rank) pairs, whose P float4 of `face` are wave-uniform loads.  Written once, read once by the fc1 GEMM:
-// bound by its 5 x 1 KB of stores per pair.  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
+// bound by its 5 x 1 KB of stores per pair (3.7 TB/s).  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
 // reads and writes the [T, 15, 4, 256] conv output ten times; this kernel never materialises it.)
 constexpr int QF_PAIRS = 60;  // (table, rank) pairs per block
 template <int P>
@@ -2052,11 +2052,14 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
       s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
       s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
     }
+    // (plain stores: y is read back by the fc1 GEMM right behind this kernel; measured 350 us per 16,384 tables against
+    //  409 us with nontemporal stores.  A block per rank -- one contiguous run of y per block -- measured 430-470 us: the
+    //  face reads then touch a new cache line per table.)
     float* dst = y + ((int64_t)r * T + t) * 5 * ystride + c;
-    __builtin_nontemporal_store(fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)), dst);
+    dst[0] = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-      __builtin_nontemporal_store(fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3])), dst + (n + 1) * ystride);
+      dst[(n + 1) * ystride] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
   }
 }
 
