@@ -1948,36 +1948,39 @@ __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ st
 // k_q_slab: the per-row stage of the ragged Q forward (game.py:95-104 -> dqn.py:56,67: policy_net(face, actions) over
 // ALL legal actions of a state; net.py:99-101 relu(fc1) -> fc2) over the slab lists, with the first layer factorised
 // per (rank, count) by the host glue (doudizhu-rl_amd/dqn_glue.py FactorisedQ.tables):
-//     q[t][j] = b2 + w2 . relu( sum_{r = 0..14} U[r][t][cnt_r(row j of table t)][:] ),   U f32 [15][T][5][256]
+//     q[t][j] = b2 + w2 . relu( sum_{r = 0..14} (U[r][cnt_r][t][:] + Z[r][cnt_r][:]) ),   cnt_r = count of rank r in row j of table t
+// U f32 [15][5][T][256] (per table), Z f32 [15][5][256] (weights only: the action plane through conv_shunzi and fc1; Z[r][0] = 0).
 // One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4l..4l+3: the all-zero-count sum
-// once per table (15 coalesced 1-KB reads), then per row two 1-KB reads per rank the action touches (of the table's own
-// 75 KB of U, L2-resident across its rows), a 4-wide dot and a DPP wave reduction.
-// The lists are read where ddz_step_slab left them (counts / rows): no CSR, no padding rows, no host sync.
+// once per table (15 coalesced 1-KB reads), then per row three 1-KB reads per rank the action touches, a 4-wide dot and
+// a DPP wave reduction.  The lists are read where ddz_step_slab left them (counts / rows): no CSR, no padding rows, no
+// host sync.
 constexpr int QH = 256;  // hidden units of fc1 (net.py:147)
-__global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, int64_t T, int tpw, const float4* __restrict__ w2,
-                                                 const float* __restrict__ b2, const int32_t* __restrict__ counts,
-                                                 const uint4* __restrict__ rows, int64_t stride, float* __restrict__ q) {
+__global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, const float4* __restrict__ Z, int64_t T, int tpw,
+                                                 const float4* __restrict__ w2, const float* __restrict__ b2,
+                                                 const int32_t* __restrict__ counts, const uint4* __restrict__ rows, int64_t stride,
+                                                 float* __restrict__ q) {
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
   const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
   const float4 w = w2[lane];
   const float bias = b2[0];
-  const int64_t rstride = T * 5 * (QH / 4);  // float4s between ranks
+  const int64_t cstride = T * (QH / 4);  // float4s between the counts of a rank; 5 of them between two ranks
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
     int n = (int)rfl((uint32_t)counts[t]);
     if (n < 0 || n > stride) n = 0;
-    const float4* ut = U + t * 5 * (QH / 4) + lane;
+    const float4* ut = U + t * (QH / 4) + lane;
+    const float4* zl = Z + lane;
     const uint4* lrow = rows + t * stride;
     float* qt = q + t * stride;
     if (n == 0) continue;
     // h0 = the sum with every count 0 (the pass): once per table; a row then swaps in the terms of the ranks it touches
-    // (an action touches 1.3 ranks on average: 2 reads per touched rank instead of 15 per row)
+    // (an action touches 1.3 ranks on average)
     float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 15; ++r) {
-      const float4 v = ut[r * rstride];
+      const float4 v = ut[r * 5 * cstride];
       h0.x += v.x; h0.y += v.y; h0.z += v.z; h0.w += v.w;
     }
     for (int j0 = 0; j0 < n; j0 += 64) {
@@ -1993,8 +1996,9 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
           const int r = __builtin_ctz(tm);
           uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
           c = c > 4u ? 4u : c;
-          const float4 v = ut[r * rstride + (int64_t)c * (QH / 4)], z = ut[r * rstride];
-          h.x += v.x - z.x; h.y += v.y - z.y; h.z += v.z - z.z; h.w += v.w - z.w;
+          if (r >= 13 && c > 1u) c = 1u;  // (a joker exists once; u holds counts 0 and 1 for ranks 13, 14)
+          const float4 v = ut[(r * 5 + (int64_t)c) * cstride], z0 = ut[r * 5 * cstride], zz = zl[(r * 5 + (int)c) * (QH / 4)];
+          h.x += v.x - z0.x + zz.x; h.y += v.y - z0.y + zz.y; h.z += v.z - z0.z + zz.z; h.w += v.w - z0.w + zz.w;
         }
         float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
         p = wave_sum_f32(p);
@@ -2008,18 +2012,25 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
 // k_q_feat: the first layer of the same forward per (table, rank, count) -- conv1..conv4 + the (1,4) max-pool of
 // net.py:92-94 (each conv_k is a (1,k) window, stride 4, on a width-4 input: ONE output column per rank; the pool is the
 // max over the four convs) -- evaluated from `face` alone, for every count cnt = 0..4 an action could take of the rank:
-//     Y[r][t][cnt][c] = max_k ( bias_k[c] + sum_{plane, slot < k} W_k[c][plane][slot] * face[t][plane][r][slot] + A[cnt][k][c] )
+//     Y[r][cnt][t][c] = max_k ( bias_k[c] + sum_{plane, slot < k} W_k[c][plane][slot] * face[t][plane][r][slot] + A[cnt][k][c] )
+// (cnt-major inside a rank: the fc1 GEMM then takes counts 0..4 of ranks 3..2 and only counts 0..1 of the two jokers)
 // A[cnt][k][c] = the action plane's thermometer (envi.py:139-146: slots < cnt set) through conv_k.  One block of 256
-// threads = the 256 channels; a thread keeps its channel's weights in registers (P * 10 + 4 + 16 floats) and walks over
-// (table, rank) pairs, whose P float4 of `face` are wave-uniform loads.  Written once, read once by the fc1 GEMM:
-// bound by its 5 x 1 KB of stores per pair (3.7 TB/s).  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
+// threads = the 256 channels; a thread keeps its channel's weights in registers (P * 10 + 4 + 16 floats); the block's 16
+// tables of `face` are staged in LDS and read back as broadcasts; the loop is rank-major so that the stores of a (rank,
+// count) are one 16-KB run of y.  Written once, read once by the fc1 GEMM: bound by its 5 x 1 KB of stores per pair.  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
 // reads and writes the [T, 15, 4, 256] conv output ten times; this kernel never materialises it.)
-constexpr int QF_PAIRS = 60;  // (table, rank) pairs per block
+constexpr int QF_TILE = 16;  // tables per block
 template <int P>
 __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                const float* __restrict__ bias, const float* __restrict__ acnt,
                                                float* __restrict__ y, int64_t ystride) {
   const int c = threadIdx.x;
+  // the block's tile of `face` (QF_TILE tables x P x 15 float4: one contiguous piece) goes through LDS: coalesced loads,
+  // then wave-uniform (broadcast) LDS reads per (table, rank) pair
+  __shared__ float4 s_face[QF_TILE * P * 15];
+  const int64_t tb = (int64_t)blockIdx.x * QF_TILE;
+  const int nt = (int)(T - tb < QF_TILE ? T - tb : QF_TILE);
+  for (int i = threadIdx.x; i < nt * P * 15; i += QH) s_face[i] = face[tb * P * 15 + i];
   // this channel's weights: wf [P * 4][4 * 256] (row = plane * 4 + slot, column = k * 256 + c; slots >= k + 1 are zero)
   float w[P][10];
 #pragma unroll
@@ -2037,29 +2048,28 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
 #pragma unroll
     for (int n = 0; n < 4; ++n) a[n][k] = acnt[((n + 1) * 4 + k) * QH + c];  // counts 1..4 (count 0 adds nothing)
   }
-  const int64_t npairs = T * 15;
-  const int64_t p0 = (int64_t)blockIdx.x * QF_PAIRS;
-  const int64_t p1 = p0 + QF_PAIRS < npairs ? p0 + QF_PAIRS : npairs;
-  for (int64_t pr = p0; pr < p1; ++pr) {  // pair = t * 15 + r (the order of `face`'s rows)
-    const int64_t t = pr / 15;
-    const int r = (int)(pr - t * 15);
-    float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
+  __syncthreads();
+  const int64_t cs = T * ystride;  // between two counts of a rank
+  // rank-major over the tile: for a (rank, count) the tile's tables are consecutive rows of y -- QF_TILE KB per run
+  for (int r = 0; r < 15; ++r) {
+    const int ncnt = r < 13 ? 4 : 1;  // a joker exists once: counts 2..4 of ranks 13, 14 are never read
+    float* dst = y + ((int64_t)r * 5 * T + tb) * ystride + c;
+    for (int ti = 0; ti < nt; ++ti) {
+      float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const float4 x = face[(t * P + p) * 15 + r];  // wave-uniform address
-      s0 += w[p][0] * x.x;
-      s1 += w[p][1] * x.x + w[p][2] * x.y;
-      s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
-      s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+      for (int p = 0; p < P; ++p) {
+        const float4 x = s_face[(ti * P + p) * 15 + r];  // wave-uniform address: an LDS broadcast
+        s0 += w[p][0] * x.x;
+        s1 += w[p][1] * x.x + w[p][2] * x.y;
+        s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
+        s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+      }
+      // (plain stores: y is read back by the fc1 GEMM right behind this kernel)
+      float* d = dst + ti * ystride;
+      d[0] = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+      for (int n = 0; n < ncnt; ++n)
+        d[(n + 1) * cs] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
     }
-    // (plain stores: y is read back by the fc1 GEMM right behind this kernel; measured 350 us per 16,384 tables against
-    //  409 us with nontemporal stores.  A block per rank -- one contiguous run of y per block -- measured 430-470 us: the
-    //  face reads then touch a new cache line per table.)
-    float* dst = y + ((int64_t)r * T + t) * 5 * ystride + c;
-    dst[0] = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-      dst[(n + 1) * ystride] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
   }
 }
 
@@ -2989,7 +2999,7 @@ int ddz_q_features(int device, const float* face, int64_t n_tables, int planes, 
   if (n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
-  const dim3 grid((unsigned)((n_tables * 15 + QF_PAIRS - 1) / QF_PAIRS)), block(QH);
+  const dim3 grid((unsigned)((n_tables + QF_TILE - 1) / QF_TILE)), block(QH);
   hipStream_t st = (hipStream_t)stream;
   const float4* f = (const float4*)face;
   switch (planes) {
@@ -3002,11 +3012,11 @@ int ddz_q_features(int device, const float* face, int64_t n_tables, int planes, 
   return check_launch();
 }
 
-int ddz_q_slab(ddz_env_t* e, const float* u, int64_t hidden, const float* w2, const float* b2, const int32_t* counts,
-               const int8_t* rows, int64_t stride, float* q, void* stream) {
+int ddz_q_slab(ddz_env_t* e, const float* u, const float* z, int64_t hidden, const float* w2, const float* b2,
+               const int32_t* counts, const int8_t* rows, int64_t stride, float* q, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (!al(u, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4)) return DDZ_EINVAL;
-  if (!u || !w2 || !b2 || !counts || !rows || !q || hidden != QH || stride < 1) return DDZ_EINVAL;
+  if (!al(u, 16) || !al(z, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4)) return DDZ_EINVAL;
+  if (!u || !z || !w2 || !b2 || !counts || !rows || !q || hidden != QH || stride < 1) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   // one table per wave up to 16 waves per CU, then consecutive tables per wave (as the stepping kernels)
@@ -3014,7 +3024,7 @@ int ddz_q_slab(ddz_env_t* e, const float* u, int64_t hidden, const float* w2, co
   const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
   const int64_t per_block = (int64_t)WPB * tpw;
   hipLaunchKernelGGL(k_q_slab, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
-                     (const float4*)u, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q);
+                     (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q);
   return check_launch();
 }
 

@@ -96,8 +96,8 @@ def td_target(transitions, q_next, gamma=0.95):
 # weights -- the same for every rank, and cnt = 0 for every rank the action does not touch.  fc1 is linear, so its
 # pre-activation is a sum over the 15 ranks of U[r, t, cnt_r, :] = fc1_r @ Y[t, r, cnt_r, :] (+ the conv_shunzi
 # branch, linear end to end, folded in: a per-table vector and a per-(rank, count) vector).  Per iteration:
-#     tables(face)  -> U [15, T, 5, 256]   dense, fixed shapes, plain torch GEMMs (hipBLASLt) -- no ragged dimension
-#     per legal row -> q = fc2(relu(sum_r U[r, t, cnt_r]))   a 15-way gather-sum + a 256-dot per row
+#     tables(face)  -> U [15, 5, T, 256]   dense, fixed shapes, plain torch GEMMs (hipBLASLt) -- no ragged dimension
+#     per legal row -> q = fc2(relu(sum_r U[r, cnt_r, t] + Z[r, cnt_r]))   a gather-sum + a 256-dot per row
 # The per-row stage runs over the slab lists in the engine (ddz_q_slab: no CSR, no host sync, no padded rows), or
 # over CSR rows with plain torch ops (q_csr: the reference statement, used by the tests).
 import torch.nn as nn  # noqa: E402
@@ -140,8 +140,6 @@ class QNet(nn.Module):
 class FactorisedQ:
     """Inference form of a QNet: the weight-only tables of the factorisation above, cached until the weights change
     (refresh() is called automatically when a parameter's version counter moved).  Eval semantics (no dropout)."""
-    KP = 264  # K of the second GEMM: 256 channels + 5 one-hot count columns (the conv_shunzi action part) + 3 pad
-
     def __init__(self, net, chunk_tables=16384):
         self.net, self.chunk = net, int(chunk_tables)
         self.P = net.planes
@@ -175,13 +173,14 @@ class FactorisedQ:
         Ws = n.conv_shunzi.weight[:, :, :, 0]                          # [H, C, 15]
         Mz = torch.einsum("ocw,cpr->prwo", W1z, Ws)                    # [C, 15, 4, H1]: conv_shunzi then fc1, composed
         self.Mz_f = Mz[:P].reshape(P * 60, H1).contiguous()            # face part: one GEMM per table
-        Zr = torch.zeros((15, 5, H1), dtype=dt, device=dev)            # action part per (rank, count)
-        Zr[:, 1:] = Mz[C - 1].cumsum(dim=1)
+        Z = torch.zeros((15, 5, H1), dtype=dt, device=dev)             # action part per (rank, count): weights only
+        Z[:, 1:] = Mz[C - 1].cumsum(dim=1)
+        self.Z = Z.contiguous()
         self.base = (n.fc1.bias + torch.einsum("ocw,c->o", W1z, n.conv_shunzi.bias)).contiguous()
-        W2 = torch.zeros((15, self.KP, H1), dtype=dt, device=dev)
-        W2[:, :H] = W1y.permute(2, 1, 0)                               # [r, c, o]
-        W2[:, H:H + 5] = Zr
-        self.W2 = W2.contiguous()
+        W2 = W1y.permute(2, 1, 0).contiguous()                         # [r, c, o]: fc1 per rank
+        # one GEMM batch per (rank, count): ranks 3..2 have counts 0..4 (65 batches), the two jokers counts 0..1
+        self.W2_main = W2[:13, None].expand(13, 5, H, H1).reshape(65, H, H1).contiguous()
+        self.W2_jok = [W2[r, None].expand(2, H, H1).contiguous() for r in (13, 14)]
         self.w2 = n.fc2.weight[0].contiguous()
         self.b2 = n.fc2.bias.detach().clone()
         self.H, self.H1 = H, H1
@@ -193,8 +192,7 @@ class FactorisedQ:
         if key not in self._ws:
             if len(self._ws) > 3:
                 self._ws.clear()
-            Y = torch.zeros((15, Tc, 5, self.KP), dtype=torch.float32, device=dev)
-            Y[:, :, :, self.H:self.H + 5] = torch.eye(5, dtype=torch.float32, device=dev)   # one-hot of the count
+            Y = torch.zeros((15, 5, Tc, self.H), dtype=torch.float32, device=dev)
             S = tmp = None
             if not fused:
                 S = torch.empty((15 * Tc, 4, self.H), dtype=torch.float32, device=dev)
@@ -204,10 +202,11 @@ class FactorisedQ:
 
     @torch.no_grad()
     def tables(self, face, out=None, fused=None):
-        """face f32 [T,P,15,4] -> U f32 [15,T,5,H1]: fc1's pre-activation contribution of rank r when the action takes
-        cnt cards of it (the per-table terms -- fc1 bias, the face part of conv_shunzi -- ride on rank 0).  Fixed shapes,
-        no host sync; tables are processed in chunks to bound the workspace.
-        fused (default: on a GPU): Y = max-pooled first layer per (rank, table, count) comes from the engine's
+        """face f32 [T,P,15,4] -> U f32 [15,5,T,H1]: fc1's pre-activation contribution of rank r when the action takes
+        cnt cards of it (the per-table terms -- fc1 bias, the face part of conv_shunzi -- ride on rank 0; counts 2..4 of
+        the two joker ranks are never written: pass a zero-initialised `out`).  Fixed shapes, no host sync; tables are
+        processed in chunks to bound the workspace.
+        fused (default: on a GPU): Y = max-pooled first layer per (rank, count, table) comes from the engine's
         ddz_q_features in one pass over `face`; fused=False is the same stage in plain torch ops (the statement the
         kernel is tested against; it reads and writes the [T,15,4,256] conv output ten times)."""
         if self._ver != self._versions():
@@ -217,9 +216,10 @@ class FactorisedQ:
             raise ValueError(f"face must be [T,{P},15,4]")
         if fused is None:
             fused = face.is_cuda
-        U = out if out is not None else torch.empty((15, T, 5, H1), dtype=torch.float32, device=face.device)
-        if tuple(U.shape) != (15, T, 5, H1) or not U.is_contiguous():
-            raise ValueError("out must be a contiguous [15,T,5,256] tensor")
+        U = out if out is not None else torch.zeros((15, 5, T, H1), dtype=torch.float32, device=face.device)
+        if tuple(U.shape) != (15, 5, T, H1) or not U.is_contiguous():
+            raise ValueError("out must be a contiguous [15,5,T,256] tensor")
+        U75 = U.view(75, T, H1)
         for t0 in range(0, T, self.chunk):
             t1 = min(T, t0 + self.chunk)
             Tc = t1 - t0
@@ -233,10 +233,12 @@ class FactorisedQ:
                 torch.addmm(self.bias_f, X, self.Wf, out=S.view(15 * Tc, 4 * H))
                 for cnt in range(5):
                     torch.add(S, self.A[cnt], out=tmp)
-                    Y[:, :, cnt, :H] = tmp.amax(dim=1).view(15, Tc, H)  # max over the four convs = the (1,4) max-pool
-            Uc = U[:, t0:t1]
-            torch.bmm(Y.view(15, Tc * 5, self.KP), self.W2, out=Uc.view(15, Tc * 5, H1))
-            Uc[0] += (torch.addmm(self.base, f.reshape(Tc, P * 60), self.Mz_f)).view(Tc, 1, H1)
+                    Y[:, cnt] = tmp.amax(dim=1).view(15, Tc, H)        # max over the four convs = the (1,4) max-pool
+            Y75 = Y.view(75, Tc, H)
+            torch.bmm(Y75[:65], self.W2_main, out=U75[:65, t0:t1])     # ranks 3..2, counts 0..4
+            for k, r in enumerate((13, 14)):                           # the jokers: counts 0, 1
+                torch.bmm(Y75[5 * r: 5 * r + 2], self.W2_jok[k], out=U75[5 * r: 5 * r + 2, t0:t1])
+            U[0, :, t0:t1] += torch.addmm(self.base, f.reshape(Tc, P * 60), self.Mz_f)
         return U
 
     @torch.no_grad()
@@ -244,20 +246,22 @@ class FactorisedQ:
         """The per-row stage with plain torch ops over CSR lists (the statement the engine's ddz_q_slab is tested
         against): rows int8 [N,16] count rows (ddz_legal / ddz_slab_to_csr; rows beyond offsets[T] are padding and get
         some table's value), offsets int32 [T+1] -> q f32 [N].  No host sync: N is the buffer size."""
-        T = U.shape[1]
+        T = U.shape[2]
         N = rows.shape[0]
         pos = torch.arange(N, device=rows.device, dtype=offsets.dtype)
         seg = torch.searchsorted(offsets[1:].contiguous(), pos, right=True).clamp_(max=T - 1).long()
         cnt = rows[:, :15].long().clamp_(0, 4)
-        idx = (torch.arange(15, device=rows.device)[None, :] * T + seg[:, None]) * 5 + cnt      # [N,15] into U.view(-1, H1)
-        h = F.embedding_bag(idx, U.view(-1, self.H1), mode="sum")
+        cnt[:, 13:] = cnt[:, 13:].clamp(max=1)                            # a joker exists once
+        rc = torch.arange(15, device=rows.device)[None, :] * 5 + cnt      # [N,15]: (rank, count)
+        h = F.embedding_bag(rc * T + seg[:, None], U.view(-1, self.H1), mode="sum")
+        h = h + F.embedding_bag(rc, self.Z.view(-1, self.H1), mode="sum")
         return F.relu(h) @ self.w2 + self.b2
 
     @torch.no_grad()
     def q_slab(self, env, U, out=None):
         """The per-row stage over the engine's slab lists (ddz_q_slab): q f32 [T, stride], entries beyond counts[t]
         untouched.  Feeds env.policy_step_slab / select_slab."""
-        return env.q_slab(U, self.w2, self.b2, out=out)
+        return env.q_slab(U, self.Z, self.w2, self.b2, out=out)
 
 
 def ragged_q(net, face, rows, offsets):
@@ -284,7 +288,7 @@ class PolicyLoop:
         self.variant, self.epsilon, self.auto_reset = int(face_variant), float(epsilon), bool(auto_reset)
         T = env.T
         self.face = env.observe(self.variant)
-        self.U = torch.empty((15, T, 5, self.fq.H1), dtype=torch.float32, device=env.device)
+        self.U = torch.zeros((15, 5, T, self.fq.H1), dtype=torch.float32, device=env.device)
         self.q = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=env.device)
         self.choice = torch.empty(T, dtype=torch.int32, device=env.device)
         if not env._slab_fresh:

@@ -236,24 +236,26 @@ class BatchedEnv:
                                        _stream(self.device)))
         return out
 
-    def q_slab(self, u, w2, b2, out=None):
+    def q_slab(self, u, z, w2, b2, out=None):
         """Per-row stage of the ragged Q forward over the current slab lists (ddz_q_slab; dqn_glue.FactorisedQ):
-        u f32 [15,T,5,256], w2 f32 [256], b2 f32 [1] (device tensors) -> q f32 [T, stride], valid in [:, :counts[t]]."""
+        u f32 [15,5,T,256], z f32 [15,5,256], w2 f32 [256], b2 f32 [1] (device tensors) -> q f32 [T, stride], valid in
+        [:, :counts[t]]."""
         if not self._slab_fresh:
             self.legal_slab()
         H = int(u.shape[-1])
-        if u.dtype != torch.float32 or tuple(u.shape) != (15, self.T, 5, H) or not u.is_contiguous() or u.device != self.device:
-            raise ValueError("u must be a contiguous float32 [15,T,5,hidden] tensor on the engine's device")
+        if u.dtype != torch.float32 or tuple(u.shape) != (15, 5, self.T, H) or not u.is_contiguous() or u.device != self.device:
+            raise ValueError("u must be a contiguous float32 [15,5,T,hidden] tensor on the engine's device")
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
         w2 = w2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
         b2 = b2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
-        if w2.numel() != H or b2.numel() != 1:
-            raise ValueError("w2 must be [hidden], b2 [1]")
+        if w2.numel() != H or b2.numel() != 1 or z.numel() != 75 * H:
+            raise ValueError("z must be [15,5,hidden], w2 [hidden], b2 [1]")
         if out is None:
             out = torch.zeros((self.T, self.slab_stride), dtype=torch.float32, device=self.device)
         elif out.dtype != torch.float32 or out.numel() != self.T * self.slab_stride or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32 [T, stride] tensor")
-        check(self.lib.ddz_q_slab(self._h, _p(u), H, _p(w2), _p(b2), self._pp["counts"], self._pp["rows"], self.slab_stride,
-                                  _p(out), _stream(self.device)))
+        check(self.lib.ddz_q_slab(self._h, _p(u), _p(z), H, _p(w2), _p(b2), self._pp["counts"], self._pp["rows"],
+                                  self.slab_stride, _p(out), _stream(self.device)))
         return out
 
     def legal_onehot(self):
@@ -473,14 +475,15 @@ def state_prob(known60, size1, size2, device="cuda:0"):
 
 def q_features(face, wf, bias, acnt, y):
     """ddz_q_features: first layer of the ragged Q forward per (table, rank, count) from `face` f32 [T,P,15,4] into
-    y f32 [15,T,5,K] (K >= 256; columns >= 256 are left alone).  dqn_glue.FactorisedQ.tables drives it."""
+    y f32 [15,5,T,K] (K >= 256; columns >= 256 and counts 2..4 of the joker ranks are left alone).
+    dqn_glue.FactorisedQ.tables drives it."""
     L = _lib.lib()
     dev = _require_gpu(face.device)
     T, P = int(face.shape[0]), int(face.shape[1])
     if face.dtype != torch.float32 or tuple(face.shape[2:]) != (15, 4) or not face.is_contiguous():
         raise ValueError("face must be a contiguous float32 [T,P,15,4] tensor")
-    if y.dtype != torch.float32 or tuple(y.shape[:3]) != (15, T, 5) or not y.is_contiguous() or y.device != dev:
-        raise ValueError("y must be a contiguous float32 [15,T,5,K] tensor on the same device")
+    if y.dtype != torch.float32 or tuple(y.shape[:3]) != (15, 5, T) or not y.is_contiguous() or y.device != dev:
+        raise ValueError("y must be a contiguous float32 [15,5,T,K] tensor on the same device")
     for w, n in ((wf, P * 4 * 1024), (bias, 1024), (acnt, 5 * 4 * 256)):
         if w.dtype != torch.float32 or w.numel() != n or not w.is_contiguous() or w.device != dev:
             raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")

@@ -41,7 +41,7 @@ def main():
         net = glue.QNet(6).to(dev).eval()
         fq = glue.FactorisedQ(net)
         face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=dev)
-        U = torch.empty((15, T, 5, fq.H1), dtype=torch.float32, device=dev)
+        U = torch.zeros((15, 5, T, fq.H1), dtype=torch.float32, device=dev)
         qbuf = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=dev)
     stats = torch.zeros((T, 2), dtype=torch.int64, device=dev)
     nodes = torch.zeros(2, dtype=torch.int64, device=dev)

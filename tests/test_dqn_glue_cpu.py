@@ -109,6 +109,7 @@ def _random_faces_and_rows(T, P, seed):
     N = int(offsets[-1])
     rows = torch.zeros((N + 7, 16), dtype=torch.int8)                 # 7 padding rows behind offsets[T]
     rows[:, :15] = ((torch.rand(N + 7, 15, generator=g) < 0.2) * torch.randint(1, 5, (N + 7, 15), generator=g)).to(torch.int8)
+    rows[:, 13:15].clamp_(max=1)                                      # a joker exists once (count rows of the action space)
     rows[0, :15] = 0                                                  # a pass
     return face, rows, offsets, counts, N
 

@@ -155,7 +155,7 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         U = fq.tables(face)                            # first layer by ddz_q_features (one pass over `face`)
         U_torch = fq.tables(face, fused=False)         # ... and the same stage in plain torch ops
         assert torch.allclose(U, U_torch, rtol=1e-5, atol=1e-5), float((U - U_torch).abs().max())
-        q = env.q_slab(U, fq.w2, fq.b2)
+        q = env.q_slab(U, fq.Z, fq.w2, fq.b2)
         off, rows, _ = env.slab_to_csr(rows_per_table=512)
         qc = fq.q_csr(U, rows, off)
         n = int(off[-1].item())
