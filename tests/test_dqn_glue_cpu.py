@@ -187,3 +187,40 @@ def test_replay_and_td_step():
     for _ in range(10):
         l1 = float(glue.td_step(policy, target, opt, b))
     assert l1 < l0
+
+
+def test_qnet_and_ragged_q_against_the_references_own_networks(golden):
+    """Fixture G9 (tests/golden/gen_qnet.py): q values computed by the reference's OWN classes (net.py:66-150, forward
+    net.py:81-102) right after torch.manual_seed(seed), eval mode.  dqn_glue.QNet built after the same seed has the same
+    parameters (same constructors in the same order: checked through per-parameter checksums, so a mismatch means
+    "different initial weights", not "different function"), its literal forward reproduces the reference's q (same ops:
+    1e-6), and the factorised inference form agrees to 1e-5 -- for all four networks, in both calling conventions
+    (batch of (state, action) rows; one state with all its actions, dqn.py:56).  Plus the TD target of dqn.py:40-41."""
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    g = golden("qnet.npz")
+    for P in (4, 7, 9, 6):
+        torch.manual_seed(int(g[f"p{P}_seed"]))
+        net = glue.QNet(P).eval()
+        sd = net.state_dict()
+        names = [str(x) for x in g[f"p{P}_param_names"]]
+        assert names == sorted(sd) and [str(tuple(sd[k].shape)) for k in names] == [str(x) for x in g[f"p{P}_param_shapes"]]
+        sums = np.array([[float(sd[k].double().sum()), float((sd[k].double() ** 2).sum())] for k in names])
+        assert np.allclose(sums, g[f"p{P}_param_sums"], rtol=1e-9, atol=1e-9), "the seeded initial weights differ from the reference's"
+        face, actions = torch.from_numpy(g[f"p{P}_face"]), torch.from_numpy(g[f"p{P}_actions"])
+        want, want1 = torch.from_numpy(g[f"p{P}_q"]), torch.from_numpy(g[f"p{P}_q_single"])
+        with torch.no_grad():
+            q = net(face, actions)[:, 0]
+            q1 = net(face[0], actions[: want1.numel()])[:, 0]
+        assert float((q - want).abs().max()) < 1e-6 and float((q1 - want1).abs().max()) < 1e-6
+        # the inference form: every (state, action) pair as a one-row segment; then one state with 7 actions
+        n = face.shape[0]
+        rows = torch.zeros((n, 16), dtype=torch.int8)
+        rows[:, :15] = actions.sum(dim=2).round().to(torch.int8)          # onehot2arr (envi.py:148-157)
+        offsets = torch.arange(n + 1, dtype=torch.int32)
+        assert float((glue.ragged_q(net, face, rows, offsets) - want).abs().max()) < 1e-5
+        m = want1.numel()
+        off1 = torch.tensor([0, m], dtype=torch.int32)
+        assert float((glue.ragged_q(net, face[:1], rows[:m], off1) - want1).abs().max()) < 1e-5
+    batch = {"reward": torch.from_numpy(g["td_r"]), "done": torch.from_numpy(g["td_done"]) > 0}
+    y = glue.td_target(batch, torch.from_numpy(g["td_qnext"]), float(g["gamma"]))
+    assert torch.allclose(y, torch.from_numpy(g["td_y"]), rtol=0, atol=1e-6)
