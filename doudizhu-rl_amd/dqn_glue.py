@@ -338,6 +338,15 @@ class Replay:
                 "reward": self.r[idx], "done": self.done[idx]}
 
 
+EPSILON_HIGH, EPSILON_LOW, DECAY = 0.5, 0.01, int((8000 * (2 / 3)) / 5)   # config.py:9-13
+
+
+def epsilon_schedule(episode, high=EPSILON_HIGH, low=EPSILON_LOW, decay=DECAY):
+    """DQNFirst.update_epsilon (dqn.py:73-76): low + (high - low) * exp(-episode / decay)."""
+    import math
+    return low + (high - low) * math.exp(-1.0 * episode / decay)
+
+
 def td_step(policy, target, optimizer, batch, gamma=0.95):
     """One perceive() update (dqn.py:33-48): y = r + (1 - done) * gamma * Q_target(s1, a1), MSE against
     Q_policy(s0, a0), one optimizer step.  Returns the loss (a tensor: no host sync)."""

@@ -65,3 +65,53 @@ out["hyper"] = np.array([rconf.EPSILON_HIGH, rconf.EPSILON_LOW, rconf.REPLAY_SIZ
                          rconf.UPDATE_TARGET_EVERY], dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, "qnet.npz"), **out)
 print("wrote qnet.npz:", {k: v.shape for k, v in out.items() if k.endswith("_q")}, os.path.getsize(os.path.join(HERE, "qnet.npz")), "bytes")
+
+# ---- G10: one DQNFirst.perceive() update (dqn.py:21-48) of the reference's own agent, as numbers
+import random  # noqa: E402
+
+import dqn as rdqn  # noqa: E402  (reference, container only)
+
+torch.manual_seed(4242)
+agent = rdqn.DQNFirst(rnet.NetCooperationSimplify)     # policy + target (train mode: dropout is active, net.py / dqn.py as written)
+g = torch.Generator().manual_seed(77)
+B, P = rconf.BATCH_SIZE, 6
+
+
+def therm(cnt):
+    return (cnt[..., None] > torch.arange(4)).float()
+
+
+s0 = therm(torch.randint(0, 5, (B, P, 15), generator=g)); s1 = therm(torch.randint(0, 5, (B, P, 15), generator=g))
+a0 = therm((torch.rand(B, 15, generator=g) < 0.2) * torch.randint(1, 5, (B, 15), generator=g))
+a1 = therm((torch.rand(B, 15, generator=g) < 0.2) * torch.randint(1, 5, (B, 15), generator=g))
+rew = torch.tensor([0.0, 100.0, -100.0, 50.0, -50.0])[torch.randint(0, 5, (B,), generator=g)]
+done = rew != 0
+a1[done] = 0                                           # game.py:122-123: zeros at the terminal ply
+for i in range(B - 1):
+    agent.replay_buffer.append((s0[i], a0[i], float(rew[i]), s1[i], a1[i], bool(done[i])))
+random.seed(99)
+order = random.sample(range(B), B)                     # the positions perceive()'s own random.sample will draw
+random.seed(99)
+loss = agent.perceive(s0[B - 1], a0[B - 1], float(rew[B - 1]), s1[B - 1], a1[B - 1], bool(done[B - 1]))
+sd = agent.policy_net.state_dict()
+names = sorted(sd)
+more = {"td_seed": np.int64(4242), "td_order": np.array(order, np.int64), "td_loss": np.float64(loss),
+        "td_s0": s0.numpy().astype(np.uint8), "td_a0": a0.numpy().astype(np.uint8), "td_s1": s1.numpy().astype(np.uint8),
+        "td_a1": a1.numpy().astype(np.uint8), "td_rew": rew.numpy(), "td_done_b": done.numpy(),
+        "td_after_names": np.array(names),
+        "td_after_sums": np.array([[float(sd[k].double().sum()), float((sd[k].double() ** 2).sum())] for k in names]),
+        "td_lr": np.float64(1e-4)}
+out.update(more)
+# ---- the epsilon schedule (dqn.py:73-76) and the checkpoint directory convention (config.py:30-31), as the reference computes them
+eps_at = [0, 1, 100, 1066, 5000, 20000]
+eps = []
+for e in eps_at:
+    agent.update_epsilon(e)
+    eps.append(float(agent.epsilon))
+out["eps_episodes"], out["eps_values"] = np.array(eps_at, np.int64), np.array(eps, np.float64)
+nd_names = ["0805_1409_lord_4000", "0808_0854_up_3000_61", "a_b", "plain", "x_y_z_w_v"]
+out["name_dir_in"] = np.array(nd_names)
+out["name_dir_out"] = np.array([rconf.name_dir(n) for n in nd_names])
+out["name_dir_out_split1"] = np.array([rconf.name_dir(n, 1) for n in nd_names])
+np.savez_compressed(os.path.join(HERE, "qnet.npz"), **out)
+print("G10: loss", loss, "file", os.path.getsize(os.path.join(HERE, "qnet.npz")), "bytes")
