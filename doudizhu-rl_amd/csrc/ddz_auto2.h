@@ -511,7 +511,88 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       }
     }
     const int npass = A2_PASSES;
+#ifdef DDZ_STAMP
+    int n_fastpass = 0, n_genpass = 0;
+#endif
     for (int pass = pass0; pass < npass && nitems < target; ++pass) {
+#ifndef DDZ_A2_NO_FASTPASS
+      {  // the common pass: every item has its own lane (nitems < target = 64) and ALL children fit the list -- count,
+         // scan and emit from registers, the fitting candidates remembered as a bit mask (no class histogram, no
+         // tcnt / tcards round trip).  Same list as the general pass below with tau = 0.
+        const bool mine = lane < nitems;
+        uint64_t A = 0, B = 0, K = 0, fm = 0;
+        uint32_t M = 0, I = 0;
+        if (mine) { A = W.itA[cur][lane]; B = W.itB[cur][lane]; M = W.itM[cur][lane]; I = W.itI[cur][lane]; K = W.itK[cur][lane]; }
+        const bool open = mine && (A | B) != 0;
+        int cnt = mine ? 1 : 0, pr = -1, lo = 0, ul = 0;
+        bool wide = false;
+        if (open) {
+          pr = a2_pend_rank(A, B);
+          if (pr >= 0) {
+            cnt = 1 + (a2_pair_option(q.hand, B, pr) ? 1 : 0);
+          } else {
+            ul = a2_lowrank(A);
+            const int from = (int)((I >> 14) & 1023);
+            lo = from != A2_NOFROM ? from : a2_bs(bsw0, bsw1, bsw2, ul);
+            const int hi = a2_bs(bsw0, bsw1, bsw2, ul + 1);
+            if (hi - lo > 64) {
+              wide = true;
+            } else {
+              for (int p = lo; p < hi; ++p)
+                if (a2_fits(W.cn[p], A)) fm |= 1ull << (p - lo);
+            }
+            cnt = __popcll(fm);
+          }
+        }
+        const int grow = wave_sum_i32(open ? cnt - 1 : 0);
+        if (__ballot(wide) == 0 && nitems + grow <= A2_CAP) {
+          if (__ballot(open) == 0) break;  // only finished combinations are left: the list in `cur` stands
+          const int nxt = cur ^ 1;
+          const int oin = wave_scan_add(cnt);
+          int w = oin - cnt;
+          if (mine && !open) {
+            W.itA[nxt][w] = A; W.itB[nxt][w] = B; W.itM[nxt][w] = M; W.itI[nxt][w] = I; W.itK[nxt][w] = K;
+          } else if (open) {
+            const int sum2 = (int)(M & 1023) - 512, cvmin = (int)(int8_t)((M >> 10) & 0xFF), nact = (int)((M >> 18) & 31);
+            const int idmin = (int)(I & 0x3FFF);
+            auto put = [&](uint64_t A2, uint64_t B2, int v2, bool el, int id, int fromc, int dig) {
+              int cv = cvmin, im = idmin;
+              if (el && (cvmin == AUTO_NONE || v2 < cvmin)) { cv = v2; im = id; }
+              W.itA[nxt][w] = A2; W.itB[nxt][w] = B2;
+              W.itM[nxt][w] = (uint32_t)((sum2 + v2 + 512) & 1023) | ((uint32_t)(cv & 0xFF) << 10) | ((uint32_t)(nact + 1) << 18);
+              W.itI[nxt][w] = (uint32_t)im | ((uint32_t)fromc << 14);
+              W.itK[nxt][w] = K | a2_keydigit(nact, dig);
+              ++w;
+              ++nodes_l;
+            };
+            if (pr >= 0) {
+              put(A, B - (1ull << (4 * pr)), a2_single_v2(pr), (q.esingle >> pr) & 1u, 1 + pr, A2_NOFROM, 1);
+              if (cnt == 2) put(A, B - (2ull << (4 * pr)), a2_pair_v2(pr), (q.epair >> pr) & 1u, 16 + pr, A2_NOFROM, 2);
+            } else {
+              for (uint64_t m = fm; m; m &= m - 1) {
+                const int pp = lo + __builtin_ctzll(m);
+                const uint64_t nib = W.cn[pp];
+                const uint32_t ci = W.ci[pp];
+                uint64_t A2, B2;
+                a2_child(q, A, B, nib, A2, B2);
+                const bool same = !q.nosplit && a2_lowrank(A2) == ul;
+                put(A2, B2, (int)(int8_t)((ci >> 14) & 0xFF), (ci >> 22) & 1u, (int)(ci & 0x3FFF), same ? pp : A2_NOFROM, pp + 1);
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          nitems = (int)rl((uint32_t)oin, 63);
+          cur = nxt;
+#ifdef DDZ_STAMP
+          ++n_fastpass;
+#endif
+          continue;
+        }
+      }
+#endif
+#ifdef DDZ_STAMP
+      ++n_genpass;
+#endif
       // (a) children count and cards left of every item; extra slots wanted per cards-left class
       if (lane < 24) W.hist[lane] = 0;
       __builtin_amdgcn_wave_barrier();
@@ -906,7 +987,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
 #ifdef DDZ_STAMP
     if (g_stamps && lane == 0) {
       g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];
-      g_stamps[16 * t + 3] = nitems_final; g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
+      g_stamps[16 * t + 3] = (unsigned long long)nitems_final | ((unsigned long long)n_fastpass << 16) | ((unsigned long long)n_genpass << 24); g_stamps[16 * t + 4] = nodes; g_stamps[16 * t + 5] = n;
       g_stamps[16 * t + 6] = n_trips; g_stamps[16 * t + 7] = n_lane_trips;
       for (int k_ = 0; k_ < 2; ++k_) g_stamps[16 * t + 8 + k_] = tsec[k_];
       g_stamps[16 * t + 10] = (unsigned long long)(blockIdx.x * A2_WPB + wv);  // which wave decided it, when (timeline)

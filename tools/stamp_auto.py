@@ -38,6 +38,9 @@ torch.cuda.synchronize()
 assert raw.ddz_debug_set_stamps(None) == 0
 s = buf.cpu().numpy().astype(np.float64)
 s = s[(ids.cpu().numpy() >= 0)]
+passes = s[:, 3].astype(np.int64)
+s[:, 3] = passes & 0xFFFF
+print(f"  frontier passes per decision: register pass {((passes >> 16) & 0xFF).mean():.2f}, general pass {((passes >> 24) & 0xFF).mean():.2f}")
 print(f"T={T}: {len(s)} decisions, launch {e0.elapsed_time(e1) * 1e3:.0f} us; cycles per decision (s_memtime)")
 for k, nm in enumerate(["staging + sort", "frontier passes", "search"]):
     print(f"  {nm:18s} mean {s[:, k].mean():9.0f}  p50 {np.percentile(s[:, k], 50):9.0f}  p99 {np.percentile(s[:, k], 99):9.0f}  max {s[:, k].max():9.0f}")
