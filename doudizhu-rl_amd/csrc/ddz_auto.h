@@ -40,7 +40,8 @@ struct AutoArgs {
   int32_t* status;
   uint32_t* ticket;         // k_auto2: this launch's own zeroed ticket word -- tables are handed out through it
   const int32_t* order;     // k_auto2, STATE form: the tables to decide, heaviest hands first (k_auto_order), or null
-  const uint32_t* order_hdr;  // ... and its header (AutoOrder: [0..3] bucket sizes, [8] queue length; device words)
+  const uint32_t* order_hdr;  // ... and its header (AutoOrder: [0] queue length, [2] positions drawn one by one; device words)
+  int teams;                // k_auto2: waves that find the queue empty help the searches still running in their block
   double rp[24];            // round_penalty by min_oppo_cards (rule_based_model.py:57), computed on the host
 };
 

@@ -55,6 +55,7 @@ constexpr int F_ENUM = 1, F_STEP = 2, F_RESET = 4, F_COUNT = 8, F_SLAB = 16;
 // ------------------------------------------------------------------------------------
 // scratch layout (caller-owned, zero-filled at create)
 constexpr int AUTO_SLOTS = 4;  // ring of k_auto2 queue slots per handle (concurrent launches on several streams)
+constexpr int AO_HDR_BYTES = 576;  // sizeof(AutoOrder), ddz_auto2.h
 struct Layout {
   int64_t T, nblk;
   int64_t off_counts, off_local, off_blk_tot, off_blk_stats, off_status, off_auto, auto_slot_bytes, bytes;
@@ -69,7 +70,7 @@ inline Layout make_layout(int64_t T) {
   l.off_local = o;      o = align_up(o + 2 * T * 4, 256);
   l.off_blk_tot = o;    o = align_up(o + 2 * l.nblk * 4, 256);
   l.off_blk_stats = o;  o = align_up(o + T * 32, 256);           // one slot per wave (<= T)
-  l.auto_slot_bytes = align_up(64 + 4 * T, 256);                  // AutoOrder header + order[T]
+  l.auto_slot_bytes = align_up(AO_HDR_BYTES + 4 * T, 256);        // AutoOrder header + order[T]
   l.off_auto = o;       o = align_up(o + AUTO_SLOTS * l.auto_slot_bytes, 256);
   l.off_status = o;     o = align_up(o + 64, 256);               // (the last 256 bytes: callers of the stateless entry
   l.bytes = o;                                                    //  points read the status word at bytes - 256)
@@ -2362,6 +2363,7 @@ struct ddz_env {
   int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
   uint32_t auto_next; // next slot of the k_auto2 queue ring
   int slab_lpt;       // k_slab: block work list of deals + lists, heaviest first (tpw >= 2)
+  int auto_teams;     // k_auto2: waves without tables help the searches of their block
 };
 
 namespace {
@@ -2444,8 +2446,7 @@ constexpr int AUTO_K_SEQUENTIAL = 1, AUTO_K_LANES = 2, AUTO_K_LANES_TABLE_ORDER 
 static int launch_auto_ordered(ddz_env* e, AutoArgs& a, hipStream_t st) {
   uint8_t* slot_mem = (uint8_t*)e->scratch + e->lay.off_auto + (int64_t)(e->auto_next++ % AUTO_SLOTS) * e->lay.auto_slot_bytes;
   AutoOrder* slot = (AutoOrder*)slot_mem;
-  int32_t* order = (int32_t*)(slot_mem + 64);
-  static_assert(sizeof(AutoOrder) == 64, "slot header");
+  int32_t* order = (int32_t*)(slot_mem + AO_HDR_BYTES);
   const hipError_t r = hipMemsetAsync(slot, 0, sizeof(AutoOrder), st);
   if (r != hipSuccess) return hip_fail(r);
   const dim3 grid((unsigned)((a.T + AO_BT - 1) / AO_BT)), block(AO_BT);
@@ -2454,7 +2455,7 @@ static int launch_auto_ordered(ddz_env* e, AutoArgs& a, hipStream_t st) {
   int rc = check_launch();
   if (rc) return rc;
   a.ticket = &slot->ticket; a.order = order; a.order_hdr = (const uint32_t*)slot;
-  static_assert(offsetof(AutoOrder, total) == 32 && offsetof(AutoOrder, cnt) == 0, "k_auto2 reads words 0, 1 and 8");
+  static_assert(offsetof(AutoOrder, total) == 0 && offsetof(AutoOrder, nsingle) == 8, "k_auto2 reads words 0 and 2");
   hipLaunchKernelGGL(k_auto2<true>, dim3((unsigned)auto_blocks(e->device, a.T)), dim3(A2_TB), 0, st, a);
   return check_launch();
 }
@@ -2531,6 +2532,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
   e->slab_lpt = e->tpw >= 2;
+  e->auto_teams = 1;
   *out = e;
   return DDZ_OK;
 }
@@ -2884,7 +2886,7 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   if (!g.ok) return DDZ_ENODEV;
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
-  a.status = e->sc.status;
+  a.status = e->sc.status; a.teams = e->auto_teams;
   fill_round_penalty(a);
   return launch_auto_ordered(e, a, (hipStream_t)stream);
 }
@@ -2900,7 +2902,7 @@ int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_
   if (!g.ok) return DDZ_ENODEV;
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
-  a.status = e->sc.status;
+  a.status = e->sc.status; a.teams = e->auto_teams;
   fill_round_penalty(a);
   if (kernel == AUTO_K_LANES) return launch_auto_ordered(e, a, (hipStream_t)stream);
   return launch_auto<true>(e->device, a, (hipStream_t)stream, kernel == AUTO_K_SEQUENTIAL ? AUTO_K_SEQUENTIAL : AUTO_K_LANES);
@@ -2923,6 +2925,13 @@ int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int
   return DDZ_OK;
 }
 
+int ddz_debug_set_auto_teams(ddz_env_t* e, int on) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (on < 0 || on > 1) return DDZ_EINVAL;
+  e->auto_teams = on;
+  return DDZ_OK;
+}
+
 int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const uint8_t* info, int64_t n, int32_t* ids,
                     int64_t* stats, void* stream) {
   if (!al(hands, 16) || !al(lasts, 16) || !al(info, 4) || !al(ids, 4) || !al(stats, 8)) return DDZ_EINVAL;
@@ -2933,7 +2942,7 @@ int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const 
   if (rc) return rc;
   AutoArgs a{};
   a.hands = (const uint4*)hands; a.lasts = (const uint4*)lasts; a.info = (const uint32_t*)info;
-  a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = nullptr;
+  a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = nullptr; a.teams = 1;
   fill_round_penalty(a);
   return launch_auto<false>(device, a, (hipStream_t)stream);
 }

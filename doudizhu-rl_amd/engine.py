@@ -47,7 +47,7 @@ class BatchedEnv:
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
                  want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None,
-                 _debug_slab_work_list=None):
+                 _debug_slab_work_list=None, _debug_auto_teams=None):
         # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
         # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
         self.native_joker_kickers = bool(native_joker_kickers)
@@ -85,6 +85,9 @@ class BatchedEnv:
             check(self.lib.ddz_debug_set_geometry(h, int(_debug_tables_per_wave or 0),
                                                   -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop)),
                                                   -1 if _debug_slab_work_list is None else int(bool(_debug_slab_work_list))))
+        if _debug_auto_teams is not None:
+            # test hook: auto_choose's wavefronts without tables help their workgroup's running searches (default) or not
+            check(self.lib.ddz_debug_set_auto_teams(h, int(bool(_debug_auto_teams))))
 
     def close(self):
         if getattr(self, "_h", None):

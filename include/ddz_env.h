@@ -304,9 +304,14 @@ int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int3
  * 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads no environment
  * variables.                                                                                                     */
 int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_work_list);
+/* test hook: ddz_auto_choose_state's wavefronts that run out of tables help the searches still running in their
+ * workgroup (1, the default) or leave (0).  Same ids and stats either way (tests compare them).                   */
+int ddz_debug_set_auto_teams(ddz_env_t* env, int on);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
- * bit2 invalid `last` combo.  Copies 4 bytes D2H on `stream` and synchronises it.      */
+ * bit2 invalid `last` combo, bit3 a wait of ddz_auto_choose_state's cooperating wavefronts hit its
+ * hang guard (never in a working launch; the ids of that launch are not to be trusted).
+ * Copies 4 bytes D2H on `stream` and synchronises it.                                   */
 int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);
 
 /* test hook: CardGroup.to_cardgroup (card.py:327-335) of arbitrary count rows int8[n][16] ->

@@ -26,8 +26,10 @@ env.reset()
 env.legal_slab()
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):   # mid-game states of rule farmers against a random lord
     env.step_auto(0b101, slab=True)
+if len(sys.argv) > 4:  # teams off
+    env.lib.ddz_debug_set_auto_teams(env._h, int(sys.argv[4]))
 ROLES = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0b111
-buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
+buf = torch.zeros((T + 1, 16), dtype=torch.int64, device="cuda")
 assert raw.ddz_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,6 +38,9 @@ ids = env.auto_choose(ROLES)
 e1.record()
 torch.cuda.synchronize()
 assert raw.ddz_debug_set_stamps(None) == 0
+dbg = buf[T].cpu().numpy()
+buf = buf[:T]
+print(f"  teams: opened {dbg[0]}, helper stints {dbg[1]}, items put {dbg[2]} in {dbg[6]} rounds, taken {dbg[3]} in {dbg[7]} rounds; nodes walked by helpers {dbg[4]}, by owners of teams {dbg[5]}")
 s = buf.cpu().numpy().astype(np.float64)
 s = s[(ids.cpu().numpy() >= 0)]
 passes = s[:, 3].astype(np.int64)
@@ -63,6 +68,9 @@ for w, a_, b_ in zip(wave, t_start, t_end):
     last_end[w] = max(last_end[w], b_ - t0); first_start[w] = min(first_start[w], a_ - t0); busy[w] += b_ - a_; ndec[w] += 1
 print(f"  timeline: span {span:.0f} cycles over {nw} waves; per wave: decisions {ndec.mean():.1f}, busy {busy.mean():.0f} "
       f"({busy.mean() / span:.0%} of the span), first start {first_start.mean():.0f}, last end mean {last_end.mean():.0f} min {last_end.min():.0f}")
+own_span = np.array([last_end[w] - first_start[w] for w in range(nw) if ndec[w] > 0])
+print(f"  per wave (its own clock): first start to last end mean {own_span.mean():.0f} max {own_span.max():.0f} cycles; busy {busy[ndec > 0].mean():.0f} "
+      f"= {busy[ndec > 0].mean() / own_span.max():.0%} of the longest wave -- the rest is the launch's tail")
 order_ = np.argsort(t_start)
 dur = (t_end - t_start)[order_]
 q = len(dur) // 10
