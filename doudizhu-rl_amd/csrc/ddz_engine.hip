@@ -45,7 +45,7 @@ using namespace ddz;
 namespace {
 
 constexpr int BLOCK = 256;       // threads per block of the thread-per-item kernels
-constexpr int WPB = 8;           // wavefronts per block of k_table
+constexpr int WPB = 16;          // wavefronts per block of k_table and k_slab (one block per CU: one work list for 256 tables)
 constexpr int TB = WPB * 64;     // threads per block of k_table
 constexpr int STATE_ROW_BYTES = DDZ_NFIELDS * DDZ_ROW;  // 176
 
