@@ -225,7 +225,8 @@ def other_config_legs(pkg, torch, dev):
                                              "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
     # configs[2] as SURVEY 8(d) defines it: EnvCooperationSimplify planes + NetCooperationSimplify (net.py:137-150)
     # randomly initialised (torch.manual_seed(0)), eval mode, greedy arg-max per table over its legal list -- the
-    # network IN the loop (dqn_glue.PolicyLoop: dense per-table GEMMs -> ddz_q_slab -> ddz_policy_step_slab, no host sync)
+    # network IN the loop (dqn_glue.PolicyLoop: per-rank GEMMs over the rows the actors' hands allow -> ddz_q_slab_packed ->
+    # ddz_policy_step_slab)
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
     torch.manual_seed(0)
     net = glue.QNet(6).to(dev).eval()
@@ -235,7 +236,8 @@ def other_config_legs(pkg, torch, dev):
     dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.3, max_reps=64)
     s1 = env.stats()
     dtn, repn = timed_loop(lambda: [loop.q_values() for _ in range(5)], sync, min_s=0.15, max_reps=64)
-    dtt, rept = timed_loop(lambda: [loop.fq.tables(loop.face, out=loop.U) for _ in range(5)], sync, min_s=0.15, max_reps=64)
+    dtt, rept = timed_loop(lambda: [loop.fq.tables_packed(loop.face, env.actor_hands()) for _ in range(5)], sync,
+                           min_s=0.15, max_reps=64)
     dte, repe = timed_loop(lambda: [env.policy_step_slab(loop.q, 0.0, face_variant=3, face_out=loop.face) for _ in range(5)],
                            sync, min_s=0.05, max_reps=64)
     rows_eval = s1["legal_rows"] - s0["legal_rows"]
@@ -245,8 +247,16 @@ def other_config_legs(pkg, torch, dev):
         "us_net_rows_q_slab": (dtn / (5 * repn) - dtt / (5 * rept)) * 1e6, "us_env": dte / (5 * repe) * 1e6,
         "q_evals_per_s": rows_eval / dt, "mean_legal_moves": rows_eval / max(1, s1["plies"] - s0["plies"]),
         "dtype_net": "f32", "net": "NetCooperationSimplify-shaped QNet(6 + 1 planes), torch.manual_seed(0), eval()",
-        "loop": "FactorisedQ.tables(face) [plain torch GEMMs] -> ddz_q_slab -> ddz_policy_step_slab(greedy, face = "
-                "EnvCooperationSimplify): every legal action of every table gets its Q value each iteration"}
+        "loop": "FactorisedQ.tables_packed(face, actors' hands) [ddz_q_features_packed + one torch GEMM per rank over the "
+                "(rank, count, table) rows a legal move can use] -> ddz_q_slab_packed -> ddz_policy_step_slab(greedy, face "
+                "= EnvCooperationSimplify): every legal action of every table gets its Q value each iteration; one "
+                "128-byte device -> host copy per iteration (the GEMM shapes)"}
+    del loop
+    # the same with fixed shapes (all 69 (rank, count) rows of every table, nothing on the host)
+    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, packed=False)
+    loop.run(2)
+    dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.3, max_reps=64)
+    out["tables_65536_dqn_inference"]["fixed_shapes_env_steps_per_s"] = T * 5 * reps / dt
     del loop, net
     # the stepping launch alone (uniformly random legal moves drawn in the kernel: every selection is in its list), and
     # the same with the new lists packed to CSR every iteration (what a ragged NN forward over all legal moves consumes)

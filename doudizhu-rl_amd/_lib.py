@@ -57,6 +57,10 @@ SYMBOLS = {
                                  C.c_int64, C.c_void_p]),
     "ddz_q_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_void_p, C.c_void_p]),
+    "ddz_q_features_packed": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddz_q_slab_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_action_table": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "ddz_pack_trajectory": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_auto_choose_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1956,10 +1956,18 @@ __global__ __launch_bounds__(BLOCK) void k_select(const uint8_t* __restrict__ st
 // a DPP wave reduction.  The lists are read where ddz_step_slab left them (counts / rows): no CSR, no padding rows, no
 // host sync.
 constexpr int QH = 256;  // hidden units of fc1 (net.py:147)
+// PACKED (ddz_q_slab_packed): u holds only the (rank, count, table) rows a legal move can use -- rank r's rows start at
+// row0[r], its first T rows are count 0 of tables 0..T-1, the row of (r, c >= 1, t) is pidx[t][QP_OF(r, c)] -- and the
+// per-table term (fc1 bias + the face part of conv_shunzi) comes as its own [T][256] array instead of riding on rank 0.
+constexpr int QP_COLS = 64;  // pidx row: (rank r < 13, count c = 1..4) at 4 r + c - 1, the jokers' count 1 at 52, 53
+__device__ __forceinline__ int qp_col(int r, int c) { return r < 13 ? 4 * r + c - 1 : 52 + (r - 13); }
+struct QRow0 { int64_t v[16]; };  // first packed row of each rank; [15] = the number of rows
+template <bool PACKED>
 __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, const float4* __restrict__ Z, int64_t T, int tpw,
                                                  const float4* __restrict__ w2, const float* __restrict__ b2,
                                                  const int32_t* __restrict__ counts, const uint4* __restrict__ rows, int64_t stride,
-                                                 float* __restrict__ q) {
+                                                 float* __restrict__ q, const int32_t* __restrict__ pidx, QRow0 row0,
+                                                 const float4* __restrict__ tab) {
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
@@ -1971,17 +1979,20 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
     const int64_t t = t0 + i;
     int n = (int)rfl((uint32_t)counts[t]);
     if (n < 0 || n > stride) n = 0;
-    const float4* ut = U + t * (QH / 4) + lane;
+    const float4* ut = U + (PACKED ? 0 : t * (QH / 4)) + lane;
     const float4* zl = Z + lane;
     const uint4* lrow = rows + t * stride;
     float* qt = q + t * stride;
     if (n == 0) continue;
+    int32_t myidx = -1;  // PACKED: lane l holds pidx[t][l] (one coalesced 256-byte read per table)
+    if (PACKED) myidx = pidx[t * QP_COLS + lane];
     // h0 = the sum with every count 0 (the pass): once per table; a row then swaps in the terms of the ranks it touches
     // (an action touches 1.3 ranks on average)
     float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PACKED && tab) h0 = tab[t * (QH / 4) + lane];
 #pragma unroll
     for (int r = 0; r < 15; ++r) {
-      const float4 v = ut[r * 5 * cstride];
+      const float4 v = PACKED ? ut[(row0.v[r] + t) * (QH / 4)] : ut[r * 5 * cstride];
       h0.x += v.x; h0.y += v.y; h0.z += v.z; h0.w += v.w;
     }
     for (int j0 = 0; j0 < n; j0 += 64) {
@@ -1998,7 +2009,17 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
           uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
           c = c > 4u ? 4u : c;
           if (r >= 13 && c > 1u) c = 1u;  // (a joker exists once; u holds counts 0 and 1 for ranks 13, 14)
-          const float4 v = ut[(r * 5 + (int64_t)c) * cstride], z0 = ut[r * 5 * cstride], zz = zl[(r * 5 + (int)c) * (QH / 4)];
+          float4 v, z0;
+          if (PACKED) {
+            // (a count the actor does not hold has no row: such a move is not legal -- read rank r's count-0 row instead
+            // of faulting on a list that does not belong to this state)
+            const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, qp_col(r, (int)c));
+            z0 = ut[(row0.v[r] + t) * (QH / 4)];
+            v = pr >= 0 ? ut[(int64_t)pr * (QH / 4)] : z0;
+          } else {
+            v = ut[(r * 5 + (int64_t)c) * cstride]; z0 = ut[r * 5 * cstride];
+          }
+          const float4 zz = zl[(r * 5 + (int)c) * (QH / 4)];
           h.x += v.x - z0.x + zz.x; h.y += v.y - z0.y + zz.y; h.z += v.z - z0.z + zz.z; h.w += v.w - z0.w + zz.w;
         }
         float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
@@ -2021,10 +2042,12 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
 // count) are one 16-KB run of y.  Written once, read once by the fc1 GEMM: bound by its 5 x 1 KB of stores per pair.  (The torch statement of the same stage -- FactorisedQ.tables(fused=False) --
 // reads and writes the [T, 15, 4, 256] conv output ten times; this kernel never materialises it.)
 constexpr int QF_TILE = 16;  // tables per block
-template <int P>
+// PACKED (ddz_q_features_packed): only the rows a legal move can use are written, at the packed positions k_q_slab reads.
+template <int P, bool PACKED>
 __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                const float* __restrict__ bias, const float* __restrict__ acnt,
-                                               float* __restrict__ y, int64_t ystride) {
+                                               float* __restrict__ y, int64_t ystride, const int32_t* __restrict__ pidx,
+                                               QRow0 row0) {
   const int c = threadIdx.x;
   // the block's tile of `face` (QF_TILE tables x P x 15 float4: one contiguous piece) goes through LDS: coalesced loads,
   // then wave-uniform (broadcast) LDS reads per (table, rank) pair
@@ -2032,6 +2055,9 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
   const int64_t tb = (int64_t)blockIdx.x * QF_TILE;
   const int nt = (int)(T - tb < QF_TILE ? T - tb : QF_TILE);
   for (int i = threadIdx.x; i < nt * P * 15; i += QH) s_face[i] = face[tb * P * 15 + i];
+  __shared__ int32_t s_pidx[PACKED ? QF_TILE * QP_COLS : 1];  // PACKED: the tile's rows of pidx (one coalesced 4-KB read)
+  if (PACKED)
+    for (int i = threadIdx.x; i < nt * QP_COLS; i += QH) s_pidx[i] = pidx[tb * QP_COLS + i];
   // this channel's weights: wf [P * 4][4 * 256] (row = plane * 4 + slot, column = k * 256 + c; slots >= k + 1 are zero)
   float w[P][10];
 #pragma unroll
@@ -2054,7 +2080,9 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
   // rank-major over the tile: for a (rank, count) the tile's tables are consecutive rows of y -- QF_TILE KB per run
   for (int r = 0; r < 15; ++r) {
     const int ncnt = r < 13 ? 4 : 1;  // a joker exists once: counts 2..4 of ranks 13, 14 are never read
-    float* dst = y + ((int64_t)r * 5 * T + tb) * ystride + c;
+    float* dst = y + (PACKED ? row0.v[r] + tb : (int64_t)r * 5 * T + tb) * ystride + c;
+    // (two tables per trip with the sums as halves of packed-fp32 registers -- v_pk_fma_f32, half the FMA instructions --
+    // measured slower: 0.79 -> 1.30 ms for the packed form at 65,536 tables, 196 VGPRs and ~130 moves to pair the operands)
     for (int ti = 0; ti < nt; ++ti) {
       float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
 #pragma unroll
@@ -2068,8 +2096,15 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
       // (plain stores: y is read back by the fc1 GEMM right behind this kernel)
       float* d = dst + ti * ystride;
       d[0] = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      for (int n = 0; n < ncnt; ++n)
-        d[(n + 1) * cs] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
+      for (int n = 0; n < ncnt; ++n) {
+        float* dn = d + (n + 1) * cs;
+        if (PACKED) {
+          const int32_t pr = s_pidx[ti * QP_COLS + qp_col(r, n + 1)];  // (wave-uniform: an LDS broadcast)
+          if (pr < 0) continue;
+          dn = y + (int64_t)pr * ystride + c;
+        }
+        *dn = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
+      }
     }
   }
 }
@@ -2472,6 +2507,40 @@ static int launch_auto(int device, AutoArgs& a, hipStream_t st, int kernel = AUT
   const hipError_t r = hipMemsetAsync(a.ticket, 0, sizeof(uint32_t), st);
   if (r != hipSuccess) return hip_fail(r);
   hipLaunchKernelGGL(k_auto2<STATE>, dim3((unsigned)auto_blocks(device, a.T)), dim3(A2_TB), 0, st, a);
+  return check_launch();
+}
+
+// rank_row0[15] (host): first packed row of each rank; validated against the table count (a rank has at least its T count-0 rows)
+static bool q_row0(const int64_t* rank_row0, int64_t n_rows, int64_t T, QRow0& out) {
+  if (!rank_row0 || n_rows <= 0 || n_rows > ((int64_t)1 << 31) - 1) return false;
+  for (int r = 0; r < 15; ++r) {
+    out.v[r] = rank_row0[r];
+    const int64_t end = r < 14 ? rank_row0[r + 1] : n_rows;
+    if (rank_row0[r] < 0 || end - rank_row0[r] < T) return false;
+  }
+  out.v[15] = n_rows;
+  return true;
+}
+
+template <bool PACKED>
+static int launch_q_features(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                             const float* acnt, float* y, int64_t y_row_stride, const int32_t* pidx, const QRow0& row0,
+                             void* stream) {
+  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(y, 4)) return DDZ_EINVAL;
+  if (!face || !wf || !bias || !acnt || !y || n_tables <= 0 || y_row_stride < QH) return DDZ_EINVAL;
+  if (n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  const dim3 grid((unsigned)((n_tables + QF_TILE - 1) / QF_TILE)), block(QH);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* f = (const float4*)face;
+  switch (planes) {
+    case 4: hipLaunchKernelGGL((k_q_feat<4, PACKED>), grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride, pidx, row0); break;
+    case 6: hipLaunchKernelGGL((k_q_feat<6, PACKED>), grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride, pidx, row0); break;
+    case 7: hipLaunchKernelGGL((k_q_feat<7, PACKED>), grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride, pidx, row0); break;
+    case 9: hipLaunchKernelGGL((k_q_feat<9, PACKED>), grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride, pidx, row0); break;
+    default: return DDZ_EINVAL;
+  }
   return check_launch();
 }
 
@@ -3003,22 +3072,15 @@ int ddz_select_slab(ddz_env_t* e, const float* q, const int32_t* counts, int64_t
 
 int ddz_q_features(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
                    const float* acnt, float* y, int64_t y_row_stride, void* stream) {
-  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(y, 4)) return DDZ_EINVAL;
-  if (!face || !wf || !bias || !acnt || !y || n_tables <= 0 || y_row_stride < QH) return DDZ_EINVAL;
-  if (n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
-  DeviceGuard g(device);
-  if (!g.ok) return DDZ_ENODEV;
-  const dim3 grid((unsigned)((n_tables + QF_TILE - 1) / QF_TILE)), block(QH);
-  hipStream_t st = (hipStream_t)stream;
-  const float4* f = (const float4*)face;
-  switch (planes) {
-    case 4: hipLaunchKernelGGL(k_q_feat<4>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
-    case 6: hipLaunchKernelGGL(k_q_feat<6>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
-    case 7: hipLaunchKernelGGL(k_q_feat<7>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
-    case 9: hipLaunchKernelGGL(k_q_feat<9>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y, y_row_stride); break;
-    default: return DDZ_EINVAL;
-  }
-  return check_launch();
+  return launch_q_features<false>(device, face, n_tables, planes, wf, bias, acnt, y, y_row_stride, nullptr, QRow0{}, stream);
+}
+
+int ddz_q_features_packed(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                          const float* acnt, const int32_t* row_index, const int64_t* rank_row0, int64_t n_rows, float* y,
+                          int64_t y_row_stride, void* stream) {
+  QRow0 row0;
+  if (!row_index || !al(row_index, 4) || !q_row0(rank_row0, n_rows, n_tables, row0)) return DDZ_EINVAL;
+  return launch_q_features<true>(device, face, n_tables, planes, wf, bias, acnt, y, y_row_stride, row_index, row0, stream);
 }
 
 int ddz_q_slab(ddz_env_t* e, const float* u, const float* z, int64_t hidden, const float* w2, const float* b2,
@@ -3032,8 +3094,30 @@ int ddz_q_slab(ddz_env_t* e, const float* u, const float* z, int64_t hidden, con
   int64_t v = (e->T + 4095) / 4096;
   const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
   const int64_t per_block = (int64_t)WPB * tpw;
-  hipLaunchKernelGGL(k_q_slab, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
-                     (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q);
+  hipLaunchKernelGGL(k_q_slab<false>, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
+                     (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q,
+                     (const int32_t*)nullptr, QRow0{}, (const float4*)nullptr);
+  return check_launch();
+}
+
+int ddz_q_slab_packed(ddz_env_t* e, const float* u, const int32_t* row_index, const int64_t* rank_row0, int64_t n_rows,
+                      const float* table_term, const float* z, int64_t hidden, const float* w2, const float* b2,
+                      const int32_t* counts, const int8_t* rows, int64_t stride, float* q, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(u, 16) || !al(z, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4) || !al(row_index, 4) ||
+      !al(table_term, 16))
+    return DDZ_EINVAL;
+  if (!u || !z || !w2 || !b2 || !counts || !rows || !q || !row_index || hidden != QH || stride < 1) return DDZ_EINVAL;
+  QRow0 row0;
+  if (!q_row0(rank_row0, n_rows, e->T, row0)) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  int64_t v = (e->T + 4095) / 4096;
+  const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
+  const int64_t per_block = (int64_t)WPB * tpw;
+  hipLaunchKernelGGL(k_q_slab<true>, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
+                     (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q,
+                     row_index, row0, (const float4*)table_term);
   return check_launch();
 }
 

@@ -178,6 +178,7 @@ class FactorisedQ:
         self.Z = Z.contiguous()
         self.base = (n.fc1.bias + torch.einsum("ocw,c->o", W1z, n.conv_shunzi.bias)).contiguous()
         W2 = W1y.permute(2, 1, 0).contiguous()                         # [r, c, o]: fc1 per rank
+        self.W2 = W2
         # one GEMM batch per (rank, count): ranks 3..2 have counts 0..4 (65 batches), the two jokers counts 0..1
         self.W2_main = W2[:13, None].expand(13, 5, H, H1).reshape(65, H, H1).contiguous()
         self.W2_jok = [W2[r, None].expand(2, H, H1).contiguous() for r in (13, 14)]
@@ -241,6 +242,95 @@ class FactorisedQ:
             U[0, :, t0:t1] += torch.addmm(self.base, f.reshape(Tc, P * 60), self.Mz_f)
         return U
 
+    # ---- packed form: only the (rank, count, table) rows a legal move can use ----
+    @torch.no_grad()
+    def pack(self, hands):
+        """hands int [T,15] (BatchedEnv.actor_hands: what the acting role holds) -> (row_index int32 [T,64], rank_row0):
+        the layout of ddz_q_features_packed / ddz_q_slab_packed.  A legal move takes at most hands[t][r] cards of rank r,
+        so of the 69 (rank, count) rows of a table only 15 + (cards in hand) are ever read: count 0 of every rank (rank
+        r's first T rows) and counts 1..hands[t][r] (behind them, in table order).  rank_row0 = 16 python ints (the
+        ranks' first rows, then the number of rows): ONE small device -> host copy, the only sync of the packed forward
+        (the 15 GEMM shapes depend on it)."""
+        T, dev = hands.shape[0], hands.device
+        hc = hands.clamp(0, 4)
+        hc[:, 13:] = hc[:, 13:].clamp(max=1)                           # a joker exists once
+        flat = hc.t().contiguous().view(-1)                            # rank-major [15 T]
+        excl = flat.cumsum(0) - flat                                   # ONE 1-D scan: held rows before (r, t), all ranks
+        # rank r's rows start behind the r T count-0 rows and the held rows of the ranks before it
+        first = excl.view(15, T)[:, 0] + T * torch.arange(15, device=dev)
+        host = [int(x) for x in torch.cat([first, (excl[-1] + flat[-1] + 15 * T).view(1)]).cpu()]
+        # row of (r, t, c >= 1) = rank r's start + T + (held rows of rank r before table t) + c - 1
+        base = (excl.view(15, T) + T * torch.arange(1, 16, device=dev)[:, None]).t()     # [T,15]
+        c = torch.arange(4, device=dev)
+        idx = torch.where(c < hc[:, :, None], base[:, :, None] + c, -1).to(torch.int32)   # [T,15,4]
+        row_index = torch.full((T, 64), -1, dtype=torch.int32, device=dev)
+        row_index[:, :52] = idx[:, :13].reshape(T, 52)
+        row_index[:, 52], row_index[:, 53] = idx[:, 13, 0], idx[:, 14, 0]
+        return row_index, host
+
+    @torch.no_grad()
+    def tables_packed(self, face, hands, fused=None):
+        """face f32 [T,P,15,4], hands int [T,15] -> PackedU: the rows of tables() a legal move can use (a third of them
+        at ~10 cards per hand: a third of the fc1 GEMM and of the first layer's stores), one GEMM per rank over that
+        rank's rows, the per-table term on its own.  One host sync (pack).  fused=False (CPU): the same rows gathered
+        from the plain-torch tables() -- the statement the packed kernels are tested against."""
+        if self._ver != self._versions():
+            self.refresh()
+        T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
+        if tuple(face.shape[1:]) != (P, 15, 4) or tuple(hands.shape) != (T, 15):
+            raise ValueError(f"face must be [T,{P},15,4] and hands [T,15]")
+        if fused is None:
+            fused = face.is_cuda
+        row_index, row0 = self.pack(hands)
+        n = row0[15]
+        cap = max(35 * T, n)                                           # 15 + at most 20 cards in a hand of the game
+        key = ("packed", cap, face.device)
+        if key not in self._ws:
+            self._ws[key] = (torch.zeros((cap, H), dtype=torch.float32, device=face.device),
+                             torch.zeros((cap, H1), dtype=torch.float32, device=face.device))
+        Yc, Uc = self._ws[key]
+        if fused:
+            from .engine import q_features_packed
+            q_features_packed(face.contiguous(), self.Wf, self.bias_f, self.A, row_index, row0, Yc)
+        else:
+            Y = self._first_layer_torch(face)                          # [15,5,T,H]
+            for r in range(15):
+                Yc[row0[r]: row0[r] + T] = Y[r, 0]
+            cols = [(r, c) for r in range(13) for c in range(1, 5)] + [(13, 1), (14, 1)]
+            for k, (r, c) in enumerate(cols):
+                dst = row_index[:, k].long()
+                m = dst >= 0
+                Yc[dst[m]] = Y[r, c][m]
+        for r in range(15):
+            torch.mm(Yc[row0[r]: row0[r + 1]], self.W2[r], out=Uc[row0[r]: row0[r + 1]])
+        tab = torch.addmm(self.base, face.reshape(T, P * 60), self.Mz_f)
+        return PackedU(Uc, row_index, row0, tab)
+
+    def _first_layer_torch(self, face):
+        T, P, H = face.shape[0], self.P, self.H
+        X = face.permute(2, 0, 1, 3).reshape(15 * T, P * 4)
+        S = torch.addmm(self.bias_f, X, self.Wf).view(15 * T, 4, H)
+        return torch.stack([(S + self.A[cnt]).amax(dim=1).view(15, T, H) for cnt in range(5)], dim=1)
+
+    @torch.no_grad()
+    def q_csr_packed(self, pu, rows, offsets):
+        """q_csr over packed rows (plain torch; the statement ddz_q_slab_packed is tested against)."""
+        T = pu.row_index.shape[0]
+        N = rows.shape[0]
+        pos = torch.arange(N, device=rows.device, dtype=offsets.dtype)
+        seg = torch.searchsorted(offsets[1:].contiguous(), pos, right=True).clamp_(max=T - 1).long()
+        cnt = rows[:, :15].long().clamp_(0, 4)
+        cnt[:, 13:] = cnt[:, 13:].clamp(max=1)
+        r = torch.arange(15, device=rows.device)
+        row0 = torch.tensor(pu.rank_row0[:15], device=rows.device)
+        col = torch.where(r < 13, 4 * r, 52 + (r - 13) - 0)[None, :] + torch.where(r[None, :] < 13, cnt - 1, torch.zeros_like(cnt))
+        held = pu.row_index.long()[seg[:, None], col.clamp(min=0)]
+        zero_row = row0[None, :] + seg[:, None]
+        urow = torch.where((cnt > 0) & (held >= 0), held, zero_row)
+        h = pu.u[urow].sum(1) + pu.table_term[seg]
+        h = h + F.embedding_bag(r[None, :] * 5 + cnt, self.Z.view(-1, self.H1), mode="sum")
+        return F.relu(h) @ self.w2 + self.b2
+
     @torch.no_grad()
     def q_csr(self, U, rows, offsets):
         """The per-row stage with plain torch ops over CSR lists (the statement the engine's ddz_q_slab is tested
@@ -261,7 +351,18 @@ class FactorisedQ:
     def q_slab(self, env, U, out=None):
         """The per-row stage over the engine's slab lists (ddz_q_slab): q f32 [T, stride], entries beyond counts[t]
         untouched.  Feeds env.policy_step_slab / select_slab."""
+        if isinstance(U, PackedU):
+            return env.q_slab_packed(U.u, U.row_index, U.rank_row0, U.table_term, self.Z, self.w2, self.b2, out=out)
         return env.q_slab(U, self.Z, self.w2, self.b2, out=out)
+
+
+class PackedU:
+    """FactorisedQ.tables_packed's result: u f32 [>= n_rows, 256] (fc1's pre-activation contribution of the packed (rank,
+    count, table) rows), row_index int32 [T,64], rank_row0 (16 python ints), table_term f32 [T,256]."""
+    __slots__ = ("u", "row_index", "rank_row0", "table_term")
+
+    def __init__(self, u, row_index, rank_row0, table_term):
+        self.u, self.row_index, self.rank_row0, self.table_term = u, row_index, rank_row0, table_term
 
 
 def ragged_q(net, face, rows, offsets):
@@ -275,12 +376,12 @@ def ragged_q(net, face, rows, offsets):
 
 
 class PolicyLoop:
-    """game.py:95-104 for T tables with a Q-network on every seat, one lock-step iteration per step(), nothing on the
-    host in between (no .item(), no size-dependent allocation):
+    """game.py:95-104 for T tables with a Q-network on every seat, one lock-step iteration per step(), no per-table work on
+    the host (packed: one 128-byte copy per iteration; packed=False: nothing -- no .item(), no size-dependent allocation):
         face -> FactorisedQ.tables (dense GEMMs) -> ddz_q_slab (q of every legal row, slab layout)
              -> ddz_policy_step_slab (epsilon-greedy arg-max + apply + next lists + next face, ONE launch)."""
 
-    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True):
+    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=True):
         from .engine import FACE_PLANES
         if FACE_PLANES[face_variant] != net.planes:
             raise ValueError("the network's input planes do not match the face variant")
@@ -288,7 +389,11 @@ class PolicyLoop:
         self.variant, self.epsilon, self.auto_reset = int(face_variant), float(epsilon), bool(auto_reset)
         T = env.T
         self.face = env.observe(self.variant)
-        self.U = torch.zeros((15, 5, T, self.fq.H1), dtype=torch.float32, device=env.device)
+        # packed (default): the first layer and fc1 only for the (rank, count) rows the actors' hands allow -- a third of
+        # the work -- at the price of one 128-byte device -> host copy per iteration (the 15 GEMM shapes); packed=False:
+        # fixed shapes, nothing on the host
+        self.packed = bool(packed)
+        self.U = None if self.packed else torch.zeros((15, 5, T, self.fq.H1), dtype=torch.float32, device=env.device)
         self.q = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=env.device)
         self.choice = torch.empty(T, dtype=torch.int32, device=env.device)
         if not env._slab_fresh:
@@ -296,6 +401,8 @@ class PolicyLoop:
 
     def q_values(self):
         """q [T, stride] of the current lists (valid in [:, :counts[t]])"""
+        if self.packed:
+            return self.fq.q_slab(self.env, self.fq.tables_packed(self.face, self.env.actor_hands()), out=self.q)
         self.fq.tables(self.face, out=self.U)
         return self.fq.q_slab(self.env, self.U, out=self.q)
 

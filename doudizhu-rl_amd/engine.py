@@ -261,6 +261,44 @@ class BatchedEnv:
                                   self.slab_stride, _p(out), _stream(self.device)))
         return out
 
+    def actor_hands(self):
+        """int64 [T,15]: the cards the acting role of every table holds (the state's hand row of the role in the meta
+        row) -- what a legal move can take at most of each rank."""
+        s = self.state.view(self.T, 11, 16)
+        role = s[:, F_META, 0].long().clamp_(max=2)
+        return s[:, F_HAND0:F_HAND0 + 3, :15].gather(1, role[:, None, None].expand(self.T, 1, 15))[:, 0].long()
+
+    def q_slab_packed(self, u, row_index, rank_row0, table_term, z, w2, b2, out=None):
+        """ddz_q_slab_packed: the per-row stage over packed rows (dqn_glue.FactorisedQ.pack / tables_packed):
+        u f32 [n_rows,256], row_index int32 [T,64], rank_row0 = 16 host ints (the ranks' first rows + n_rows),
+        table_term f32 [T,256] | None -> q f32 [T, stride], valid in [:, :counts[t]]."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        H = int(u.shape[-1])
+        n_rows = int(rank_row0[15])
+        if u.dtype != torch.float32 or u.dim() != 2 or u.shape[0] < n_rows or not u.is_contiguous() or u.device != self.device:
+            raise ValueError("u must be a contiguous float32 [>= n_rows, hidden] tensor on the engine's device")
+        if (row_index.dtype != torch.int32 or tuple(row_index.shape) != (self.T, 64) or not row_index.is_contiguous()
+                or row_index.device != self.device):
+            raise ValueError("row_index must be a contiguous int32 [T,64] tensor on the engine's device")
+        if table_term is not None and (table_term.dtype != torch.float32 or tuple(table_term.shape) != (self.T, H)
+                                       or not table_term.is_contiguous() or table_term.device != self.device):
+            raise ValueError("table_term must be a contiguous float32 [T,hidden] tensor on the engine's device")
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        w2 = w2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
+        b2 = b2.to(device=self.device, dtype=torch.float32).contiguous().view(-1)
+        if w2.numel() != H or b2.numel() != 1 or z.numel() != 75 * H:
+            raise ValueError("z must be [15,5,hidden], w2 [hidden], b2 [1]")
+        if out is None:
+            out = torch.zeros((self.T, self.slab_stride), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.numel() != self.T * self.slab_stride or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [T, stride] tensor")
+        r0 = (C.c_int64 * 15)(*[int(x) for x in rank_row0[:15]])
+        check(self.lib.ddz_q_slab_packed(self._h, _p(u), _p(row_index), r0, n_rows,
+                                         _p(table_term) if table_term is not None else None, _p(z), H, _p(w2), _p(b2),
+                                         self._pp["counts"], self._pp["rows"], self.slab_stride, _p(out), _stream(self.device)))
+        return out
+
     def legal_onehot(self):
         """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
         self._need_legal()
@@ -491,6 +529,28 @@ def q_features(face, wf, bias, acnt, y):
         if w.dtype != torch.float32 or w.numel() != n or not w.is_contiguous() or w.device != dev:
             raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")
     check(L.ddz_q_features(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(y), int(y.shape[3]), _stream(dev)))
+    return y
+
+
+def q_features_packed(face, wf, bias, acnt, row_index, rank_row0, y):
+    """ddz_q_features_packed: the same first layer, written only for the (rank, count, table) rows a legal move can use:
+    row_index int32 [T,64] + rank_row0 (16 host ints) as dqn_glue.FactorisedQ.pack builds them, y f32 [>= n_rows, K]."""
+    L = _lib.lib()
+    dev = _require_gpu(face.device)
+    T, P = int(face.shape[0]), int(face.shape[1])
+    n_rows = int(rank_row0[15])
+    if face.dtype != torch.float32 or tuple(face.shape[2:]) != (15, 4) or not face.is_contiguous():
+        raise ValueError("face must be a contiguous float32 [T,P,15,4] tensor")
+    if y.dtype != torch.float32 or y.dim() != 2 or y.shape[0] < n_rows or not y.is_contiguous() or y.device != dev:
+        raise ValueError("y must be a contiguous float32 [>= n_rows, K] tensor on the same device")
+    if row_index.dtype != torch.int32 or tuple(row_index.shape) != (T, 64) or not row_index.is_contiguous() or row_index.device != dev:
+        raise ValueError("row_index must be a contiguous int32 [T,64] tensor on the same device")
+    for w, n in ((wf, P * 4 * 1024), (bias, 1024), (acnt, 5 * 4 * 256)):
+        if w.dtype != torch.float32 or w.numel() != n or not w.is_contiguous() or w.device != dev:
+            raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")
+    r0 = (C.c_int64 * 15)(*[int(x) for x in rank_row0[:15]])
+    check(L.ddz_q_features_packed(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(row_index), r0, n_rows, _p(y),
+                                  int(y.shape[1]), _stream(dev)))
     return y
 
 

@@ -260,6 +260,24 @@ int ddz_q_features(int device_id, const float* face, int64_t n_tables, int plane
 int ddz_q_slab(ddz_env_t* env, const float* u, const float* z, int64_t hidden, const float* w2, const float* b2,
                const int32_t* counts, const int8_t* rows, int64_t stride, float* q, void* stream);
 
+/* The same two stages over PACKED rows: only the (rank, count, table) triples a legal move of table t can use exist -- count 0
+ * of every rank, and count c >= 1 of rank r where the actor holds at least c cards of it (15 + cards-in-hand rows per table
+ * instead of 69: a third of the fc1 GEMM).  Layout (built by the host glue from the actors' hands, FactorisedQ.pack):
+ *   rank r's rows are [rank_row0[r], rank_row0[r + 1]) (rank_row0[15] == n_rows; HOST memory, 15 entries read): the first T
+ *   of them are count 0 of tables 0..T-1, then the held counts in any order;
+ *   row_index int32 [T][64] (device): row of (r < 13, c = 1..4) at column 4 r + c - 1, of a joker's count 1 at column 52 /
+ *   53; -1 = not held (ddz_q_features_packed skips it; ddz_q_slab_packed reads the count-0 row instead: no legal move of
+ *   the table takes that count).
+ * y / u f32 [n_rows][y_row_stride / hidden]; the glue multiplies each rank's rows by that rank's fc1 block (15 GEMMs).
+ * table_term f32 [T][hidden] or NULL: the per-table term (fc1 bias + the face part of conv_shunzi), added once per table
+ * (the unpacked form carries it on rank 0's rows).  Results equal the unpacked functions' up to the GEMM's summation order. */
+int ddz_q_features_packed(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                          const float* acnt, const int32_t* row_index, const int64_t* rank_row0, int64_t n_rows, float* y,
+                          int64_t y_row_stride, void* stream);
+int ddz_q_slab_packed(ddz_env_t* env, const float* u, const int32_t* row_index, const int64_t* rank_row0, int64_t n_rows,
+                      const float* table_term, const float* z, int64_t hidden, const float* w2, const float* b2,
+                      const int32_t* counts, const int8_t* rows, int64_t stride, float* q, void* stream);
+
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
  * (rule_based/utils/card.py:34-159 order), device memory. */
 int ddz_action_table(int device_id, int8_t* rows, void* stream);

@@ -144,6 +144,48 @@ def test_factorised_q_equals_literal_conv_evaluation():
         assert float((q[:N][seg == 3] - one).abs().max()) < 1e-5
 
 
+def test_packed_rows_hold_what_a_legal_move_can_use_and_give_the_same_q():
+    """FactorisedQ.pack / tables_packed / q_csr_packed (the layout of ddz_q_features_packed / ddz_q_slab_packed): of a
+    table's 69 (rank, count) rows only count 0 of every rank and counts 1..hands[t][r] exist; every rank's rows are one
+    contiguous segment that starts with the T count-0 rows; q over the packed rows == q over the full tables (fp32,
+    1e-5: the GEMM's row count is the only difference) for rows that respect the hands -- and == the literal network."""
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    for P in (6, 4):
+        torch.manual_seed(20 + P)
+        net = glue.QNet(P).eval()
+        T = 37
+        face, rows, offsets, counts, N = _random_faces_and_rows(T, P, 300 + P)
+        g = torch.Generator().manual_seed(P)
+        hands = torch.randint(0, 5, (T, 15), generator=g)
+        hands[:, 13:].clamp_(max=1)
+        hands[0] = 0                                                   # a table that holds nothing: 15 rows
+        seg = torch.repeat_interleave(torch.arange(T), counts)
+        rows[:N, :15] = torch.minimum(rows[:N, :15].long(), hands[seg]).to(torch.int8)   # moves take what the hand holds
+        fq = glue.FactorisedQ(net)
+        row_index, row0 = fq.pack(hands)
+        assert row_index.shape == (T, 64) and row_index.dtype == torch.int32 and len(row0) == 16
+        held = torch.zeros((T, 64), dtype=torch.bool)
+        for r in range(15):
+            for c in range(1, 5 if r < 13 else 2):
+                held[:, 4 * r + c - 1 if r < 13 else 52 + r - 13] = hands[:, r] >= c
+        assert bool(((row_index >= 0) == held).all())
+        assert row0[15] == 15 * T + int(hands.clamp(max=4).sum())      # 15 + cards held, per table
+        used = row_index[row_index >= 0].long()
+        assert used.unique().numel() == used.numel()                   # no row twice
+        for r in range(15):                                            # rank r's held rows lie behind its T count-0 rows
+            cols = slice(4 * r, 4 * r + 4) if r < 13 else slice(52 + r - 13, 53 + r - 13)
+            v = row_index[:, cols][row_index[:, cols] >= 0]
+            assert bool(((v >= row0[r] + T) & (v < row0[r + 1])).all())
+        pu = fq.tables_packed(face, hands, fused=False)
+        qp = fq.q_csr_packed(pu, rows, offsets)
+        qf = fq.q_csr(fq.tables(face, fused=False), rows, offsets)
+        assert float((qp[:N] - qf[:N]).abs().max()) < 1e-5
+        acts = (rows[:N, :15].float()[:, :, None] > torch.arange(4)[None, None, :]).float()
+        with torch.no_grad():
+            want = net(face[seg], acts)[:, 0]
+        assert float((qp[:N] - want).abs().max()) < 1e-5
+
+
 def test_factorised_tables_follow_weight_updates_and_chunking():
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
     torch.manual_seed(1)

@@ -171,6 +171,20 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         with torch.no_grad():
             want = copy.deepcopy(net).cpu()(face[seg[pick]].cpu(), acts.cpu())[:, 0]
         assert float((qc[:n][pick].cpu() - want).abs().max()) < 1e-5
+        # the packed form (ddz_q_features_packed -> one GEMM per rank -> ddz_q_slab_packed): only the (rank, count) rows the
+        # actors' hands allow; the same q (fp32, 1e-5: the GEMMs differ in their row counts only)
+        pu = fq.tables_packed(face, env.actor_hands())
+        nrow = pu.rank_row0[15]
+        assert nrow == 15 * T + int(env.actor_hands().sum())
+        if T <= 1000:
+            fqc = glue.FactorisedQ(copy.deepcopy(net).cpu())
+            pu_torch = fqc.tables_packed(face.cpu(), env.actor_hands().cpu(), fused=False)
+            assert torch.equal(pu_torch.row_index, pu.row_index.cpu()) and pu_torch.rank_row0 == pu.rank_row0
+            assert torch.allclose(pu.u[:nrow].cpu(), pu_torch.u[:nrow], rtol=1e-5, atol=1e-5)
+        qp = fq.q_slab(env, pu)
+        assert float((qp[valid] - q[valid]).abs().max()) < 1e-5
+        assert bool((qp[~valid] == 0).all())
+        assert float((fq.q_csr_packed(pu, rows, off)[:n] - qc[:n]).abs().max()) < 1e-5
         assert env.status() == 0
 
 
