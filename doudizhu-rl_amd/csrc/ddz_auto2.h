@@ -931,6 +931,15 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         const bool can_give_t = act && more != 0 && (more & (0u - more)) < ((pendopen & (0u - pendopen)) | 0x80000000u) &&
                                 n0 + __builtin_ctz(more | 0x80000000u) < A2_KEYLEVELS;
         const uint64_t donors_t = __ballot(can_give_t);
+#ifdef DDZ_STAMP
+        if (in_team) {  // why lanes with work cannot give: no open level / below a pending pair option / below the key levels
+          const bool blocked_pend = act && more != 0 && !((more & (0u - more)) < ((pendopen & (0u - pendopen)) | 0x80000000u));
+          const bool blocked_key = act && more != 0 && !blocked_pend && !can_give_t;
+          const int n_act = __popcll(__ballot(act)), n_none = __popcll(__ballot(act && more == 0));
+          const int n_pend = __popcll(__ballot(blocked_pend)), n_key = __popcll(__ballot(blocked_key));
+          A2DBG(8, n_act); A2DBG(9, n_none); A2DBG(10, n_pend); A2DBG(11, n_key); A2DBG(12, __popcll(donors_t));
+        }
+#endif
         if (!in_team && donors_t && a2_peek(&s_drained) != 0 && !a2_peek(&TM.open)) {
           // the owner opens the team: waves of the block have run out of queue, this search has lasted a while and has
           // subtrees to give (and no other search of the block is being shared)

@@ -41,7 +41,6 @@ def main():
         net = glue.QNet(6).to(dev).eval()
         fq = glue.FactorisedQ(net)
         face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=dev)
-        U = torch.zeros((15, 5, T, fq.H1), dtype=torch.float32, device=dev)
         qbuf = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=dev)
     stats = torch.zeros((T, 2), dtype=torch.int64, device=dev)
     nodes = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -49,9 +48,10 @@ def main():
     @torch.no_grad()
     def lord_ids():
         """the Q-network's greedy move as a canonical action id, for every table (only the lord's tables use it): the
-        ragged forward of dqn_glue (dense per-table GEMMs + ddz_q_slab), arg-max by ddz_select_slab; no host sync"""
+        ragged forward of dqn_glue (per-rank GEMMs over the rows the actors' hands allow + ddz_q_slab_packed), arg-max by
+        ddz_select_slab"""
         env.observe(3, out=face)
-        q = fq.q_slab(env, fq.tables(face, out=U), out=qbuf)
+        q = fq.q_slab(env, fq.tables_packed(face, env.actor_hands()), out=qbuf)
         choice = env.select_slab(q)
         return env.slab_ids().gather(1, choice.clamp(min=0).long()[:, None])[:, 0].to(torch.int32)
 

@@ -41,6 +41,9 @@ assert raw.ddz_debug_set_stamps(None) == 0
 dbg = buf[T].cpu().numpy()
 buf = buf[:T]
 print(f"  teams: opened {dbg[0]}, helper stints {dbg[1]}, items put {dbg[2]} in {dbg[6]} rounds, taken {dbg[3]} in {dbg[7]} rounds; nodes walked by helpers {dbg[4]}, by owners of teams {dbg[5]}")
+if dbg[8]:
+    print(f"  members' lanes at the hand-over checks: active {dbg[8]}, of which no open level {dbg[9] / dbg[8]:.0%}, below a pending pair "
+          f"option {dbg[10] / dbg[8]:.0%}, below the key levels {dbg[11] / dbg[8]:.0%}, can give {dbg[12] / dbg[8]:.0%}")
 s = buf.cpu().numpy().astype(np.float64)
 s = s[(ids.cpu().numpy() >= 0)]
 passes = s[:, 3].astype(np.int64)
