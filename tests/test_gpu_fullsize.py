@@ -188,6 +188,37 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         assert env.status() == 0
 
 
+def test_packed_q_entry_points_reject_a_layout_that_does_not_fit_the_tables(pkg):
+    """ddz_q_features_packed / ddz_q_slab_packed check the host-side segment starts before anything is launched: every
+    rank needs at least its T count-0 rows, the starts must be ordered, the row count must fit int32 -- DDZ_EINVAL, not
+    a fault; and a held-count column of -1 (a count the actor does not hold) reads the rank's count-0 row."""
+    import importlib
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    T = 300
+    torch.manual_seed(1)
+    net = glue.QNet(6).to(_dev()).eval()
+    env = pkg.BatchedEnv(T, seed=2, device=_dev())
+    env.reset(); env.rollout_random(7); env.legal_slab()
+    face = env.observe(3)
+    fq = glue.FactorisedQ(net)
+    pu = fq.tables_packed(face, env.actor_hands())
+    good = list(pu.rank_row0)
+    for bad in ([0] * 16, good[:3] + [good[4] - T + 1] + good[4:],                             # rank 3 shorter than T rows
+                [g + (1 << 31) for g in good], good[:15] + [good[14] + T - 1]):
+        with pytest.raises((pkg.DdzError, ValueError)):   # (the host mirror rejects a row count beyond its buffer itself)
+            env.q_slab_packed(pu.u, pu.row_index, bad, pu.table_term, fq.Z, fq.w2, fq.b2)
+    with pytest.raises(pkg.DdzError):
+        pkg.q_features_packed(face, fq.Wf, fq.bias_f, fq.A, pu.row_index, [0] * 16, pu.u)
+    q = fq.q_slab(env, pu).clone()
+    # every held-count column -1: each row's q falls back to the value of the pass (all counts 0) -- no fault, finite
+    none = torch.full_like(pu.row_index, -1)
+    q0 = env.q_slab_packed(pu.u, none, good, pu.table_term, fq.Z, fq.w2, fq.b2)
+    counts = env.counts.long()
+    valid = torch.arange(env.slab_stride, device=_dev())[None, :] < counts[:, None]
+    assert bool(torch.isfinite(q0[valid]).all()) and bool(torch.isfinite(q[valid]).all())
+    assert env.status() == 0
+
+
 def test_policy_loop_with_the_q_network_full_size_with_oracle_slice(pkg, oracle):
     """configs[2] as SURVEY 8(d) defines it: 65,536 tables, EnvCooperationSimplify planes, NetCooperationSimplify
     randomly initialised (torch.manual_seed(0), eval), greedy arg-max per table -- dqn_glue.PolicyLoop, nothing on the
