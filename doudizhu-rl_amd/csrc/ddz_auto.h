@@ -87,12 +87,23 @@ struct AutoBest {
 };
 
 // one finished combination (rule_based_model.py:60-86): n actions on the path (+ the leading pass when following)
+// The score is rule_based_model.py's f64 arithmetic operation by operation: the product small_num * rp is ROUNDED before
+// it is subtracted (two roundings, as Python does them).  HIP's __dmul_rn / __dsub_rn are plain operators, and under
+// hipcc's default -ffp-contract=fast the backend fuses them into one fma (one rounding) wherever it likes -- a
+// `#pragma clang fp contract(off)` does not stop it.  It did so at one inlined site and not at another when a neighbouring
+// statement changed: the greedy descent's score then sat one ulp above the same combination's score in the search and
+// the exact branch and bound pruned every combination (round 3, caught by tests/test_gpu_auto.py).  auto_rounded() is
+// the barrier: the product exists, rounded, in a register before anything consumes it (a2_hopeless likewise).
+__device__ __forceinline__ double auto_rounded(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 __device__ __forceinline__ void auto_leaf(AutoBest& b, int sum2, int cvmin, int idmin, int n, bool follow, bool pass_ok,
                                           double rp) {
   const int L = n + (follow ? 1 : 0);
   const int small_num = (L - 1) - (L >= 14 ? 1 : 0);  // :63-66: positions 1..L-1 except j == 13 (action_space[13] = '2')
   double total = (double)sum2 * 0.5;                   // :62 (exact)
-  total = __dsub_rn(total, __dmul_rn((double)small_num, rp));  // :67
+  total = total - auto_rounded((double)small_num * rp);  // :67
   if (follow && pass_ok && total > b.value) {          // :70-74 (position 0 of every combination)
     b.value = total;
     b.move = 0;
@@ -103,7 +114,7 @@ __device__ __forceinline__ void auto_leaf(AutoBest& b, int sum2, int cvmin, int 
       b.move = idmin;
     }
     // :82-86 over the positions: the largest move_value belongs to the smallest cards_value, first position on ties
-    const double mv = __dadd_rn(__dsub_rn(total, (double)cvmin * 0.5), rp);
+    const double mv = auto_rounded(total - (double)cvmin * 0.5) + rp;  // (cvmin / 2 is exact)
     if (mv > b.value) {
       b.value = mv;
       b.move = idmin;

@@ -163,7 +163,8 @@ __device__ __forceinline__ int a2_pair_v2(int r) { return r - 7 > 0 ? 3 * (r - 7
 //   * at least Lb more actions follow, Lb = ceil(cards / largest candidate of this decision whose lowest rank is not below
 //     the lowest rank left), counted up to 4;
 //   * no action still to come is worth less than the cheapest action whose lowest rank is the lowest rank left.
-// Every operation below is monotone in these three, so the f64 result bounds the f64 score of every completion; a node
+// Every operation below is monotone in these three and rounds where auto_leaf rounds (auto_rounded: no fused multiply-
+// add across the product), so the f64 result bounds the f64 score of every completion; a node
 // is skipped only when that bound is STRICTLY below a score some finished combination has reached: neither the maximum
 // nor a tie for it is lost, whatever the order of the search.
 __device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t B, int sum2, int nact, int cvmin,
@@ -181,12 +182,12 @@ __device__ __forceinline__ bool a2_hopeless(const A2Ctx& q, uint64_t A, uint64_t
   const int Lb = 1 + (nR > M ? 1 : 0) + (nR > 2 * M ? 1 : 0) + (nR > 3 * M ? 1 : 0);
   const int L = nact + Lb + (q.follow ? 1 : 0);
   const int small_num = (L - 1) - (L >= 14 ? 1 : 0);
-  const double total = __dsub_rn((double)(sum2 + (U4 >> 1)) * 0.5, __dmul_rn((double)small_num, q.rp));
+  const double total = (double)(sum2 + (U4 >> 1)) * 0.5 - auto_rounded((double)small_num * q.rp);  // (roundings as auto_leaf's)
   // cheapest action (x 2) by lowest rank: -14 -12 -10 -8 -6 -4 -2 0 | 2 3 4 8 10 12 14 (non-decreasing)
   constexpr uint64_t VM0 = 0x00FEFCFAF8F6F4F2ull, VM1 = 0x7F0E0C0A08040302ull;
   const int m2 = (int)(int8_t)((((VM0 & lom) | (VM1 & ~lom)) >> sh) & 0xFF);
   const int cm = (cvmin == AUTO_NONE || m2 < cvmin) ? m2 : cvmin;
-  double ub = __dadd_rn(__dsub_rn(total, (double)cm * 0.5), q.rp);
+  double ub = auto_rounded(total - (double)cm * 0.5) + q.rp;
   if (q.follow && q.pass_ok && total > ub) ub = total;
   return ub < thr;
 }
