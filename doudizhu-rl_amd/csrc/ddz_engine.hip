@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
   const int64_t tb = (int64_t)blockIdx.x * QF_TILE;
   const int nt = (int)(T - tb < QF_TILE ? T - tb : QF_TILE);
   for (int i = threadIdx.x; i < nt * P * 15; i += QH) s_face[i] = face[tb * P * 15 + i];
-  __shared__ int32_t s_pidx[PACKED ? QF_TILE * QP_COLS : 1];  // PACKED: the tile's rows of pidx (one coalesced 4-KB read)
+  __shared__ __attribute__((aligned(16))) int32_t s_pidx[PACKED ? QF_TILE * QP_COLS : 4];  // PACKED: the tile's rows of pidx (one coalesced 4-KB read)
   if (PACKED)
     for (int i = threadIdx.x; i < nt * QP_COLS; i += QH) s_pidx[i] = pidx[tb * QP_COLS + i];
   // this channel's weights: wf [P * 4][4 * 256] (row = plane * 4 + slot, column = k * 256 + c; slots >= k + 1 are zero)
@@ -2096,14 +2096,21 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
       // (plain stores: y is read back by the fc1 GEMM right behind this kernel)
       float* d = dst + ti * ystride;
       d[0] = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      for (int n = 0; n < ncnt; ++n) {
-        float* dn = d + (n + 1) * cs;
-        if (PACKED) {
-          const int32_t pr = s_pidx[ti * QP_COLS + qp_col(r, n + 1)];  // (wave-uniform: an LDS broadcast)
-          if (pr < 0) continue;
-          dn = y + (int64_t)pr * ystride + c;
-        }
-        *dn = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
+      if (PACKED) {
+        // the rows of counts 1..4 of this (table, rank): ONE 16-byte LDS broadcast (columns 4 r .. 4 r + 3; a joker has
+        // one), the tests and the addresses stay in vector registers (the scalar unit was this kernel's second bound:
+        // 60 scalar instructions per (table, rank) against 93 vector ones -- 790 -> 605 us at 65,536 tables)
+        int4 pr4 = make_int4(-1, -1, -1, -1);
+        if (r < 13) pr4 = *(const int4*)&s_pidx[ti * QP_COLS + 4 * r];
+        else pr4.x = s_pidx[ti * QP_COLS + 52 + (r - 13)];
+        const uint32_t ys = (uint32_t)ystride;  // (rows x stride < 2^31: checked by the caller)
+        if (pr4.x >= 0) y[(uint32_t)pr4.x * ys + c] = fmaxf(fmaxf(s0 + a[0][0], s1 + a[0][1]), fmaxf(s2 + a[0][2], s3 + a[0][3]));
+        if (pr4.y >= 0) y[(uint32_t)pr4.y * ys + c] = fmaxf(fmaxf(s0 + a[1][0], s1 + a[1][1]), fmaxf(s2 + a[1][2], s3 + a[1][3]));
+        if (pr4.z >= 0) y[(uint32_t)pr4.z * ys + c] = fmaxf(fmaxf(s0 + a[2][0], s1 + a[2][1]), fmaxf(s2 + a[2][2], s3 + a[2][3]));
+        if (pr4.w >= 0) y[(uint32_t)pr4.w * ys + c] = fmaxf(fmaxf(s0 + a[3][0], s1 + a[3][1]), fmaxf(s2 + a[3][2], s3 + a[3][3]));
+      } else {
+        for (int n = 0; n < ncnt; ++n)
+          d[(n + 1) * cs] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
       }
     }
   }
@@ -3079,7 +3086,8 @@ int ddz_q_features_packed(int device, const float* face, int64_t n_tables, int p
                           const float* acnt, const int32_t* row_index, const int64_t* rank_row0, int64_t n_rows, float* y,
                           int64_t y_row_stride, void* stream) {
   QRow0 row0;
-  if (!row_index || !al(row_index, 4) || !q_row0(rank_row0, n_rows, n_tables, row0)) return DDZ_EINVAL;
+  if (!row_index || !al(row_index, 16) || !q_row0(rank_row0, n_rows, n_tables, row0)) return DDZ_EINVAL;
+  if (y_row_stride > 0 && n_rows > (((int64_t)1 << 31) - 1) / y_row_stride) return DDZ_ECAP;  // k_q_feat indexes y with 32 bits
   return launch_q_features<true>(device, face, n_tables, planes, wf, bias, acnt, y, y_row_stride, row_index, row0, stream);
 }
 
