@@ -24,7 +24,7 @@
 #pragma once
 
 constexpr int A2_CAND = STAGE_CAP;  // candidates per table: the proven maximum of a <= 20-card hand
-constexpr int A2_WPB = 8;         // waves per block (17 KB of LDS per wave + the shared record table)
+constexpr int A2_WPB = 8;         // waves per block (17 KB of LDS per wave + the shared record table + the team: 156 KB)
 constexpr int A2_TB = A2_WPB * 64;
 constexpr int A2_CAP = 96;        // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
 constexpr int A2_KEYLEVELS = 7;   // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
