@@ -67,6 +67,7 @@ SYMBOLS = {
     "ddz_auto_choose": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "ddz_debug_cards_value": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "ddz_debug_auto_leaf": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_auto_choose_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_debug_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ddz_debug_set_auto_teams": (C.c_int, [C.c_void_p, C.c_int]),

@@ -400,6 +400,20 @@ __global__ __launch_bounds__(TB, 4) void k_auto(AutoArgs a) {
   }
 }
 
+// test hook: auto_leaf on its own (tests/test_gpu_auto.py checks it bit for bit against the two-rounding f64 arithmetic of
+// rule_based_model.py:60-86 in numpy: the contract the exact branch and bound stands on).  in[i] = {sum2, cvmin, n, follow |
+// pass_ok << 1}
+__global__ __launch_bounds__(BLOCK) void k_debug_leaf(const int4* __restrict__ in, const double* __restrict__ rp, int64_t n,
+                                                      double* __restrict__ value, int32_t* __restrict__ move) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int4 q = in[i];
+  AutoBest b{-__builtin_inf(), -1};
+  auto_leaf(b, q.x, q.y, 7, q.z, q.w & 1, (q.w >> 1) & 1, rp[i]);
+  value[i] = b.value;
+  move[i] = b.move;
+}
+
 // test hook / fixture G7 on the device: cards_value x 2 of every action id
 __global__ __launch_bounds__(BLOCK) void k_cards_value(int8_t* __restrict__ out) {
   const int id = (int)(blockIdx.x * BLOCK + threadIdx.x);

@@ -3033,6 +3033,15 @@ int ddz_debug_cards_value(int device, int8_t* out, void* stream) {
   return check_launch();
 }
 
+int ddz_debug_auto_leaf(int device, const int32_t* in, const double* rp, int64_t n, double* value, int32_t* move, void* stream) {
+  if (!in || !rp || !value || !move || n <= 0 || !al(in, 16) || !al(rp, 8) || !al(value, 8) || !al(move, 4)) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_debug_leaf, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (const int4*)in, rp, n, value, move);
+  return check_launch();
+}
+
 int ddz_status(ddz_env_t* e, int32_t* out, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
   if (!out) return DDZ_EINVAL;

@@ -313,6 +313,11 @@ int ddz_auto_choose(int device_id, const int8_t* hands, const int8_t* lasts, con
                     int32_t* ids, int64_t* stats, void* stream);
 /* test hook: 2 * cards_value (rule_based/utils/evaluator.py:10-47) of every action id, int8[DDZ_NUM_ACTIONS] */
 int ddz_debug_cards_value(int device_id, int8_t* out, void* stream);
+/* test hook: the rule agent's score of one finished combination (rule_based_model.py:60-86) on its own: in int32[n][4] =
+ * {2 * sum of cards_value, 2 * smallest eligible cards_value or 127 = none, actions, following | pass allowed << 1},
+ * rp f64[n] = round_penalty -> value f64[n], move int32[n] (0 = pass, 7 = the eligible move, -1 = none).  The f64
+ * operations round exactly as Python's (the product small_num * rp BEFORE the subtraction): tested bit for bit.     */
+int ddz_debug_auto_leaf(int device_id, const int32_t* in, const double* rp, int64_t n, double* value, int32_t* move, void* stream);
 /* test hook: ddz_auto_choose_state with an explicit kernel: 1 = the sequential full-enumeration walk (cross-check),
  * 2 = the lane-parallel branch-and-bound kernel as ddz_auto_choose_state runs it (tables ordered heaviest hand first),
  * 3 = the same kernel in table order.  Same ids by construction.                                                  */
