@@ -2517,13 +2517,17 @@ static int launch_auto(int device, AutoArgs& a, hipStream_t st, int kernel = AUT
   return check_launch();
 }
 
-// rank_row0[15] (host): first packed row of each rank; validated against the table count (a rank has at least its T count-0 rows)
+// rank_row0[15] (host): first packed row of each rank, in any order; validated against the table count: every rank owns at
+// least its T count-0 rows, inside [0, n_rows), and no two ranks' count-0 rows overlap
 static bool q_row0(const int64_t* rank_row0, int64_t n_rows, int64_t T, QRow0& out) {
   if (!rank_row0 || n_rows <= 0 || n_rows > ((int64_t)1 << 31) - 1) return false;
   for (int r = 0; r < 15; ++r) {
     out.v[r] = rank_row0[r];
-    const int64_t end = r < 14 ? rank_row0[r + 1] : n_rows;
-    if (rank_row0[r] < 0 || end - rank_row0[r] < T) return false;
+    if (rank_row0[r] < 0 || rank_row0[r] > n_rows - T) return false;
+    for (int q = 0; q < r; ++q) {
+      const int64_t d = rank_row0[r] > rank_row0[q] ? rank_row0[r] - rank_row0[q] : rank_row0[q] - rank_row0[r];
+      if (d < T) return false;
+    }
   }
   out.v[15] = n_rows;
   return true;

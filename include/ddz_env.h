@@ -263,8 +263,9 @@ int ddz_q_slab(ddz_env_t* env, const float* u, const float* z, int64_t hidden, c
 /* The same two stages over PACKED rows: only the (rank, count, table) triples a legal move of table t can use exist -- count 0
  * of every rank, and count c >= 1 of rank r where the actor holds at least c cards of it (15 + cards-in-hand rows per table
  * instead of 69: a third of the fc1 GEMM).  Layout (built by the host glue from the actors' hands, FactorisedQ.pack):
- *   rank r's rows are [rank_row0[r], rank_row0[r + 1]) (rank_row0[15] == n_rows; HOST memory, 15 entries read): the first T
- *   of them are count 0 of tables 0..T-1, then the held counts in any order;
+ *   rank r's rows start at rank_row0[r] (HOST memory, 15 entries read; the ranks' segments in any order, not overlapping,
+ *   inside [0, n_rows); rows between segments are padding the glue's batched GEMMs may compute on): the first T rows of a
+ *   segment are count 0 of tables 0..T-1, then the held counts in any order;
  *   row_index int32 [T][64] (device): row of (r < 13, c = 1..4) at column 4 r + c - 1, of a joker's count 1 at column 52 /
  *   53; -1 = not held (ddz_q_features_packed skips it; ddz_q_slab_packed reads the count-0 row instead: no legal move of
  *   the table takes that count).

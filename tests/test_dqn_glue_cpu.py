@@ -169,13 +169,18 @@ def test_packed_rows_hold_what_a_legal_move_can_use_and_give_the_same_q():
             for c in range(1, 5 if r < 13 else 2):
                 held[:, 4 * r + c - 1 if r < 13 else 52 + r - 13] = hands[:, r] >= c
         assert bool(((row_index >= 0) == held).all())
-        assert row0[15] == 15 * T + int(hands.clamp(max=4).sum())      # 15 + cards held, per table
+        held_r = hands.clamp(max=4).sum(0)                             # held (count >= 1) rows per rank
+        starts = sorted(row0[:15])                                     # segments: disjoint, each holds its rank's rows
+        for r in range(15):
+            nxt = min([x for x in starts if x > row0[r]] + [row0[15]])
+            assert row0[r] % 256 == 0 and nxt - row0[r] >= T + int(held_r[r])
+        assert row0[15] < 1.35 * (15 * T + int(held_r.sum())) + 15 * 2048  # (little padding beyond the rounding)
         used = row_index[row_index >= 0].long()
         assert used.unique().numel() == used.numel()                   # no row twice
         for r in range(15):                                            # rank r's held rows lie behind its T count-0 rows
             cols = slice(4 * r, 4 * r + 4) if r < 13 else slice(52 + r - 13, 53 + r - 13)
             v = row_index[:, cols][row_index[:, cols] >= 0]
-            assert bool(((v >= row0[r] + T) & (v < row0[r + 1])).all())
+            assert v.numel() == int(held_r[r]) and bool(((v >= row0[r] + T) & (v < row0[r] + T + int(held_r[r]))).all())
         pu = fq.tables_packed(face, hands, fused=False)
         qp = fq.q_csr_packed(pu, rows, offsets)
         qf = fq.q_csr(fq.tables(face, fused=False), rows, offsets)

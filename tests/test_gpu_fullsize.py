@@ -175,12 +175,16 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         # actors' hands allow; the same q (fp32, 1e-5: the GEMMs differ in their row counts only)
         pu = fq.tables_packed(face, env.actor_hands())
         nrow = pu.rank_row0[15]
-        assert nrow == 15 * T + int(env.actor_hands().sum())
+        held_r = env.actor_hands().sum(0)
+        assert 15 * T + int(held_r.sum()) <= nrow < 1.35 * (15 * T + int(held_r.sum())) + 15 * 2048
         if T <= 1000:
             fqc = glue.FactorisedQ(copy.deepcopy(net).cpu())
             pu_torch = fqc.tables_packed(face.cpu(), env.actor_hands().cpu(), fused=False)
             assert torch.equal(pu_torch.row_index, pu.row_index.cpu()) and pu_torch.rank_row0 == pu.rank_row0
-            assert torch.allclose(pu.u[:nrow].cpu(), pu_torch.u[:nrow], rtol=1e-5, atol=1e-5)
+            used = torch.zeros(nrow, dtype=torch.bool)                 # the rows that exist: count 0 + the held counts
+            for r in range(15):
+                used[pu.rank_row0[r]: pu.rank_row0[r] + T + int(held_r[r])] = True
+            assert torch.allclose(pu.u[:nrow].cpu()[used], pu_torch.u[:nrow][used], rtol=1e-5, atol=1e-5)
         qp = fq.q_slab(env, pu)
         assert float((qp[valid] - q[valid]).abs().max()) < 1e-5
         assert bool((qp[~valid] == 0).all())
@@ -203,8 +207,9 @@ def test_packed_q_entry_points_reject_a_layout_that_does_not_fit_the_tables(pkg)
     fq = glue.FactorisedQ(net)
     pu = fq.tables_packed(face, env.actor_hands())
     good = list(pu.rank_row0)
-    for bad in ([0] * 16, good[:3] + [good[4] - T + 1] + good[4:],                             # rank 3 shorter than T rows
-                [g + (1 << 31) for g in good], good[:15] + [good[14] + T - 1]):
+    near = list(good)
+    near[3] = near[4] + T - 1                                            # rank 3's count-0 rows would overlap rank 4's
+    for bad in ([0] * 16, near, [g + (1 << 31) for g in good], good[:15] + [max(good[:15]) + T - 1]):
         with pytest.raises((pkg.DdzError, ValueError)):   # (the host mirror rejects a row count beyond its buffer itself)
             env.q_slab_packed(pu.u, pu.row_index, bad, pu.table_term, fq.Z, fq.w2, fq.b2)
     with pytest.raises(pkg.DdzError):
