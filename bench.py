@@ -251,6 +251,15 @@ def other_config_legs(pkg, torch, dev):
                 "(rank, count, table) rows a legal move can use] -> ddz_q_slab_packed -> ddz_policy_step_slab(greedy, face "
                 "= EnvCooperationSimplify): every legal action of every table gets its Q value each iteration; one "
                 "128-byte device -> host copy per iteration (the GEMM shapes)"}
+    hc = env.actor_hands().clamp(max=4)
+    hc[:, 13:].clamp_(max=1)
+    rows_needed = 15 * T + int(hc.sum())
+    out["tables_65536_dqn_inference"]["packed_rows_per_table"] = rows_needed / T
+    loop.fq.batched_gemm = True    # one batched fc1 GEMM over segments padded to the longest instead of fifteen exact ones
+    out["tables_65536_dqn_inference"]["batched_gemm_padding_share"] = 1.0 - rows_needed / loop.fq.pack(env.actor_hands())[1][15]
+    loop.run(2)
+    dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.2, max_reps=64)
+    out["tables_65536_dqn_inference"]["batched_gemm_env_steps_per_s"] = T * 5 * reps / dt
     del loop
     # the same with fixed shapes (all 69 (rank, count) rows of every table, nothing on the host)
     loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, packed=False)

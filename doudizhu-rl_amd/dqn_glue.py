@@ -142,6 +142,10 @@ class FactorisedQ:
     (refresh() is called automatically when a parameter's version counter moved).  Eval semantics (no dropout)."""
     def __init__(self, net, chunk_tables=16384):
         self.net, self.chunk = net, int(chunk_tables)
+        # packed form: fifteen fc1 GEMMs over exactly the rows that exist (default), or ONE batched GEMM over segments
+        # padded to the longest (True).  Measured at 65,536 tables: steady state (thousands of iterations in) 4.00 against
+        # 4.23 ms per iteration; a batch of young games (30 iterations in, 16 % padding) 3.75 against 3.60 ms.
+        self.batched_gemm = False
         self.P = net.planes
         self._ver = None
         self._ws = {}
@@ -248,13 +252,11 @@ class FactorisedQ:
         """hands int [T,15] (BatchedEnv.actor_hands: what the acting role holds) -> (row_index int32 [T,64], rank_row0):
         the layout of ddz_q_features_packed / ddz_q_slab_packed.  A legal move takes at most hands[t][r] cards of rank r,
         so of the 69 (rank, count) rows of a table only 15 + (cards in hand) are ever read: count 0 of every rank (the
-        first T rows of rank r's segment) and counts 1..hands[t][r] (behind them, in table order).  Every rank's segment
-        has the SAME length M = the longest one rounded up to 2048 rows (rank_row0[r] = r M; the rows behind a shorter
-        rank's last held count are padding, ~15 %): the 15 fc1 GEMMs are then ONE batched GEMM [15, M, 256] x [15, 256,
-        256] -- one launch instead of fifteen (each separate GEMM cost ~25 us of host time behind the sync) on the BLAS
-        library's best tile, 3.75 -> 3.6 ms per iteration at 65,536 tables (three size-sorted groups of five with ~5 %
-        padding measured slower: 3.7-3.8 ms).  rank_row0 = 16 python ints (rank r's first row; [15] = the number of rows);
-        M comes from ONE small device -> host copy (the 15 segment sizes), the only sync of the packed forward."""
+        first T rows of rank r's segment) and counts 1..hands[t][r] (behind them, in table order).  The segments follow
+        each other without gaps (fifteen GEMMs of different row counts), or -- batched_gemm -- all have the length of the
+        longest, rounded up to 2048 rows (rank_row0[r] = r M; the rows behind a shorter rank's last held count are
+        padding): ONE batched GEMM [15, M, 256] x [15, 256, 256].  rank_row0 = 16 python ints (rank r's first row; [15] =
+        the number of rows); the sizes come from ONE small device -> host copy, the only sync of the packed forward."""
         T, dev = hands.shape[0], hands.device
         hc = hands.clamp(0, 4)
         hc[:, 13:] = hc[:, 13:].clamp(max=1)                           # a joker exists once
@@ -263,10 +265,15 @@ class FactorisedQ:
         excl = (flat.cumsum(0) - flat).view(15, T)                     # ONE 1-D scan: held rows before (r, t), all ranks
         rel = T + excl - excl[:, :1]                                   # row of (r, t, count 1) inside rank r's segment
         sizes = [int(x) for x in (T + per_rank.sum(1)).cpu()]          # the sync
-        # every segment as long as the longest, rounded up to 2048 rows (a coarse grid: the GEMM's shape then repeats from
-        # iteration to iteration and the BLAS library's solution cache hits)
-        M = (max(sizes) + 2047) // 2048 * 2048
-        host = [r * M for r in range(16)]
+        if self.batched_gemm:
+            # every segment as long as the longest, rounded up to 2048 rows (a coarse grid: the GEMM's shape then repeats
+            # from iteration to iteration)
+            M = (max(sizes) + 2047) // 2048 * 2048
+            host = [r * M for r in range(16)]
+        else:                                                          # fifteen GEMMs over exactly the rows that exist
+            host = [0] * 16
+            for r in range(15):
+                host[r + 1] = host[r] + sizes[r]
         base = (rel + torch.tensor(host[:15], device=dev)[:, None]).t()   # [T,15]
         c = torch.arange(4, device=dev)
         idx = torch.where(c < hc[:, :, None], base[:, :, None] + c, -1).to(torch.int32)   # [T,15,4]
@@ -278,8 +285,8 @@ class FactorisedQ:
     @torch.no_grad()
     def tables_packed(self, face, hands, fused=None):
         """face f32 [T,P,15,4], hands int [T,15] -> PackedU: the rows of tables() a legal move can use (a third of them
-        at ~10 cards per hand: a third of the fc1 GEMM and of the first layer's stores), ONE batched GEMM over the ranks'
-        equally long segments, the per-table term on its own.  One host sync (pack).  fused=False (CPU): the same rows
+        at ~10 cards per hand: a third of the fc1 GEMM and of the first layer's stores), one GEMM per rank over that rank's
+        rows (or one batched GEMM over padded segments: batched_gemm), the per-table term on its own.  One host sync (pack).  fused=False (CPU): the same rows
         gathered from the plain-torch tables() -- the statement the packed kernels are tested against."""
         if self._ver != self._versions():
             self.refresh()
@@ -308,8 +315,12 @@ class FactorisedQ:
                 dst = row_index[:, k].long()
                 m = dst >= 0
                 Yc[dst[m]] = Y[r, c][m]
-        M = row0[1]
-        torch.bmm(Yc[:n].view(15, M, H), self.W2, out=Uc[:n].view(15, M, H1))
+        if self.batched_gemm:
+            M = row0[1]
+            torch.bmm(Yc[:n].view(15, M, H), self.W2, out=Uc[:n].view(15, M, H1))
+        else:
+            for r in range(15):
+                torch.mm(Yc[row0[r]: row0[r + 1]], self.W2[r], out=Uc[row0[r]: row0[r + 1]])
         tab = torch.addmm(self.base, face.reshape(T, P * 60), self.Mz_f)
         return PackedU(Uc, row_index, row0, tab)
 

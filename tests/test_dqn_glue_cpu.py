@@ -161,34 +161,36 @@ def test_packed_rows_hold_what_a_legal_move_can_use_and_give_the_same_q():
         hands[0] = 0                                                   # a table that holds nothing: 15 rows
         seg = torch.repeat_interleave(torch.arange(T), counts)
         rows[:N, :15] = torch.minimum(rows[:N, :15].long(), hands[seg]).to(torch.int8)   # moves take what the hand holds
-        fq = glue.FactorisedQ(net)
-        row_index, row0 = fq.pack(hands)
-        assert row_index.shape == (T, 64) and row_index.dtype == torch.int32 and len(row0) == 16
-        held = torch.zeros((T, 64), dtype=torch.bool)
-        for r in range(15):
-            for c in range(1, 5 if r < 13 else 2):
-                held[:, 4 * r + c - 1 if r < 13 else 52 + r - 13] = hands[:, r] >= c
-        assert bool(((row_index >= 0) == held).all())
-        held_r = hands.clamp(max=4).sum(0)                             # held (count >= 1) rows per rank
-        starts = sorted(row0[:15])                                     # segments: disjoint, each holds its rank's rows
-        for r in range(15):
-            nxt = min([x for x in starts if x > row0[r]] + [row0[15]])
-            assert row0[r] % 256 == 0 and nxt - row0[r] >= T + int(held_r[r])
-        assert row0[15] < 1.35 * (15 * T + int(held_r.sum())) + 15 * 2048  # (little padding beyond the rounding)
-        used = row_index[row_index >= 0].long()
-        assert used.unique().numel() == used.numel()                   # no row twice
-        for r in range(15):                                            # rank r's held rows lie behind its T count-0 rows
-            cols = slice(4 * r, 4 * r + 4) if r < 13 else slice(52 + r - 13, 53 + r - 13)
-            v = row_index[:, cols][row_index[:, cols] >= 0]
-            assert v.numel() == int(held_r[r]) and bool(((v >= row0[r] + T) & (v < row0[r] + T + int(held_r[r]))).all())
-        pu = fq.tables_packed(face, hands, fused=False)
-        qp = fq.q_csr_packed(pu, rows, offsets)
-        qf = fq.q_csr(fq.tables(face, fused=False), rows, offsets)
-        assert float((qp[:N] - qf[:N]).abs().max()) < 1e-5
-        acts = (rows[:N, :15].float()[:, :, None] > torch.arange(4)[None, None, :]).float()
-        with torch.no_grad():
-            want = net(face[seg], acts)[:, 0]
-        assert float((qp[:N] - want).abs().max()) < 1e-5
+        for batched in (False, True):   # fifteen exact segments / equally long padded ones (one batched GEMM)
+            fq = glue.FactorisedQ(net)
+            fq.batched_gemm = batched
+            row_index, row0 = fq.pack(hands)
+            assert row_index.shape == (T, 64) and row_index.dtype == torch.int32 and len(row0) == 16
+            held = torch.zeros((T, 64), dtype=torch.bool)
+            for r in range(15):
+                for c in range(1, 5 if r < 13 else 2):
+                    held[:, 4 * r + c - 1 if r < 13 else 52 + r - 13] = hands[:, r] >= c
+            assert bool(((row_index >= 0) == held).all())
+            held_r = hands.clamp(max=4).sum(0)                             # held (count >= 1) rows per rank
+            if batched:
+                M = row0[1]
+                assert M % 2048 == 0 and row0 == [r * M for r in range(16)] and T + int(held_r.max()) <= M < T + int(held_r.max()) + 2048
+            else:
+                assert [row0[r + 1] - row0[r] for r in range(15)] == [T + int(x) for x in held_r] and row0[0] == 0
+            used = row_index[row_index >= 0].long()
+            assert used.unique().numel() == used.numel()                   # no row twice
+            for r in range(15):                                            # rank r's held rows lie behind its T count-0 rows
+                cols = slice(4 * r, 4 * r + 4) if r < 13 else slice(52 + r - 13, 53 + r - 13)
+                v = row_index[:, cols][row_index[:, cols] >= 0]
+                assert v.numel() == int(held_r[r]) and bool(((v >= row0[r] + T) & (v < row0[r] + T + int(held_r[r]))).all())
+            pu = fq.tables_packed(face, hands, fused=False)
+            qp = fq.q_csr_packed(pu, rows, offsets)
+            qf = fq.q_csr(fq.tables(face, fused=False), rows, offsets)
+            assert float((qp[:N] - qf[:N]).abs().max()) < 1e-5
+            acts = (rows[:N, :15].float()[:, :, None] > torch.arange(4)[None, None, :]).float()
+            with torch.no_grad():
+                want = net(face[seg], acts)[:, 0]
+            assert float((qp[:N] - want).abs().max()) < 1e-5
 
 
 def test_factorised_tables_follow_weight_updates_and_chunking():

@@ -176,7 +176,7 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         pu = fq.tables_packed(face, env.actor_hands())
         nrow = pu.rank_row0[15]
         held_r = env.actor_hands().sum(0)
-        assert 15 * T + int(held_r.sum()) <= nrow < 1.35 * (15 * T + int(held_r.sum())) + 15 * 2048
+        assert nrow == 15 * T + int(held_r.sum())                       # fifteen exact segments (the default)
         if T <= 1000:
             fqc = glue.FactorisedQ(copy.deepcopy(net).cpu())
             pu_torch = fqc.tables_packed(face.cpu(), env.actor_hands().cpu(), fused=False)
@@ -188,6 +188,11 @@ def test_q_slab_equals_the_torch_statement_and_the_literal_network(pkg):
         qp = fq.q_slab(env, pu)
         assert float((qp[valid] - q[valid]).abs().max()) < 1e-5
         assert bool((qp[~valid] == 0).all())
+        fq.batched_gemm = True                                         # ... and ONE batched GEMM over padded segments
+        pub = fq.tables_packed(face, env.actor_hands())
+        assert pub.rank_row0[1] % 2048 == 0 and pub.rank_row0 == [r * pub.rank_row0[1] for r in range(16)]
+        assert float((fq.q_slab(env, pub)[valid] - q[valid]).abs().max()) < 1e-5
+        fq.batched_gemm = False
         assert float((fq.q_csr_packed(pu, rows, off)[:n] - qc[:n]).abs().max()) < 1e-5
         assert env.status() == 0
 
