@@ -8,17 +8,27 @@ terminal ply (game.py:109-167):
   * when any role empties its hand every role with a pending (s0, a0) gets
     (s0, a0, +/-reward_dict[role], s1 = face after the terminal ply, a1 = zeros[15,4], True)
     (game.py:113-123, :134-141, :149-155, :161-167): winners +reward, losers -reward; lord and
-    farmers are opposite sides, the two farmers win and lose together.
-Here that bookkeeping is done for T tables at once with tensor ops (any device); pending
-slots are cleared at the terminal ply (the reference never clears `*_a0` between episodes,
-SURVEY.md appendix A "quirks": not replicated).
+    farmers are opposite sides, the two farmers win and lose together; the calls come in play
+    order starting behind the winner (lord wins: down, up, lord; down wins: up, lord, down; up
+    wins: lord, down, up).
+Here that bookkeeping is done for T tables at once with tensor ops (any device).  Pinned by fixture
+G11 (tests/golden/gen_game.py: every perceive() call of the reference's own Game.play).
+
+One documented choice: the reference never clears `*_s0 / *_a0` between episodes
+(game.py:39-40,132-137; SURVEY.md appendix A "quirks"), so from the second episode of a Game
+object on, the first feedback of `down` and of `up` pushes (s0, a0 of the PREVIOUS episode's last
+move, 0, s1 = first observation of the new episode, a1, False) -- a transition across a reshuffle;
+the lord's stale pair is overwritten unseen.  Default here: pending slots are cleared at the
+terminal ply (no such transition); replicate_reference_quirk=True reproduces the reference call
+for call (both modes are checked against G11).
 
 Usage per lock-step iteration (all tensors [T, ...]):
     closed = asm.before_step(role, face, chosen_onehot, greedy_onehot)
     ... env.step(auto_reset=False) ...; terminal_face = env.observe(variant)
     ended = asm.after_step(role, done, r, terminal_face); env.reset(mask=done)
 Both calls return a dict of the transitions they closed (s0, a0, reward, s1, a1, done,
-table, role) ready to append to a replay buffer.
+table, role) ready to append to a replay buffer; within a table the rows are in the reference's
+call order.
 """
 import torch
 
@@ -26,13 +36,19 @@ REWARD_DICT = {"up": 50.0, "lord": 100.0, "down": 50.0}  # game.py:13-14; role i
 
 
 class TransitionAssembler:
-    def __init__(self, n_tables, planes, device, reward_dict=None):
+    def __init__(self, n_tables, planes, device, reward_dict=None, trained_roles=(True, True, True),
+                 replicate_reference_quirk=False):
+        """trained_roles: (up, lord, down) -- the roles whose agent keeps training (Game's train_dict, game.py:15-16,
+        :95-104,:112): only they open and close transitions.  replicate_reference_quirk: see the module docstring."""
         rd = dict(REWARD_DICT if reward_dict is None else reward_dict)
         self.T, self.P, self.device = int(n_tables), int(planes), torch.device(device)
         self.reward = torch.tensor([rd["up"], rd["lord"], rd["down"]], dtype=torch.float32, device=self.device)
+        self.trained = torch.tensor([bool(x) for x in trained_roles], dtype=torch.bool, device=self.device)
+        self.quirk = bool(replicate_reference_quirk)
         self.s0 = torch.zeros((self.T, 3, self.P, 15, 4), dtype=torch.float32, device=self.device)
         self.a0 = torch.zeros((self.T, 3, 15, 4), dtype=torch.float32, device=self.device)
         self.pending = torch.zeros((self.T, 3), dtype=torch.bool, device=self.device)
+        self.fresh = torch.ones(self.T, dtype=torch.bool, device=self.device)   # no ply of the episode played yet
 
     @staticmethod
     def _pack(s0, a0, reward, s1, a1, done, table, role):
@@ -42,22 +58,28 @@ class TransitionAssembler:
     def before_step(self, role, face, chosen, greedy, active=None):
         """role int[T] actor of each table, face f32[T,P,15,4] its observation, chosen / greedy
         f32[T,15,4] the action it is about to play and the greedy action (a1 of the closing
-        transition, game.py:125).  Closes the actor's previous transition, opens a new one."""
+        transition, game.py:125).  Closes the actor's previous transition, opens a new one.
+        active bool[T]: tables that move in this iteration (default all)."""
         role = role.to(self.device).long()
         ar = torch.arange(self.T, device=self.device)
         if active is None:
             active = torch.ones(self.T, dtype=torch.bool, device=self.device)
-        close = self.pending[ar, role] & active
+        active = active.to(self.device).bool()
+        act_tr = active & self.trained[role]
+        # the first ply of an episode (the lord's) has no feedback in front of it (game.py:129-130): whatever the slot
+        # still holds is overwritten unseen
+        close = self.pending[ar, role] & act_tr & ~self.fresh
         idx = close.nonzero(as_tuple=True)[0]
         r_idx = role[idx]
         out = self._pack(self.s0[idx, r_idx].clone(), self.a0[idx, r_idx].clone(),
                          torch.zeros(idx.numel(), dtype=torch.float32, device=self.device),
                          face[idx].clone(), greedy[idx].clone(),
                          torch.zeros(idx.numel(), dtype=torch.bool, device=self.device), idx, r_idx)
-        act = active.nonzero(as_tuple=True)[0]
+        act = act_tr.nonzero(as_tuple=True)[0]
         self.s0[act, role[act]] = face[act]
         self.a0[act, role[act]] = chosen[act]
         self.pending[act, role[act]] = True
+        self.fresh &= ~active
         return out
 
     def after_step(self, role, done, r, terminal_face):
@@ -65,7 +87,11 @@ class TransitionAssembler:
         won; rule_play.py:14), terminal_face f32[T,P,15,4] = env.observe() after the ply.
         Closes every pending transition of the finished tables."""
         done = done.to(self.device).bool()
+        role = role.to(self.device).long()
         t_idx, r_idx = (self.pending & done[:, None]).nonzero(as_tuple=True)
+        # the reference's call order: play order (lord, down, up) starting behind the winner = the actor of this ply
+        order = torch.argsort(t_idx * 3 + (r_idx - role[t_idx] - 1) % 3)
+        t_idx, r_idx = t_idx[order], r_idx[order]
         lord_won = (r.to(self.device)[t_idx] < 0)
         is_lord = r_idx == 1
         sign = torch.where(lord_won == is_lord, 1.0, -1.0)
@@ -73,7 +99,9 @@ class TransitionAssembler:
                          sign * self.reward[r_idx], terminal_face[t_idx].clone(),
                          torch.zeros((t_idx.numel(), 15, 4), dtype=torch.float32, device=self.device),
                          torch.ones(t_idx.numel(), dtype=torch.bool, device=self.device), t_idx, r_idx)
-        self.pending[done] = False
+        if not self.quirk:
+            self.pending[done] = False
+        self.fresh |= done
         return out
 
 

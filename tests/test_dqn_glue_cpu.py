@@ -34,7 +34,7 @@ def _reference_loop(oracle, seed, n_plies):
         if done[0]:                                        # terminal feedback: game.py:134-141, :149-167
             tface = env.observe(P_VARIANT)[0].copy()
             lord_won = r[0] < 0
-            for x in sorted(pend):
+            for x in sorted(pend, key=lambda x: (x - role - 1) % 3):   # the reference's call order (game.py:134-167)
                 s0, a0 = pend[x]
                 rew = REWARD[x] if (x == 1) == lord_won else -REWARD[x]
                 out.append((0, x, s0, a0, rew, tface, np.zeros((15, 4), np.float32), True))

@@ -36,6 +36,16 @@ def test_g8_choose_matches_reference(oracle, g):
     assert (ncards > 10).sum() > 500 and (ncards <= 10).sum() > 500
 
 
+def test_g8_heavy_choose_matches_reference(oracle, golden):
+    """G8h: 416 game states above G8's 4,000-combination cap (up to 44,776), each run through the reference's choose()."""
+    h = golden("rule_agent_heavy.npz")
+    assert len(h["choice"]) >= 400 and h["combinations"].min() > 4000 and h["combinations"].max() > 40000
+    for k in range(len(h["choice"])):
+        last = h["last"][k] if h["last"][k].any() else None
+        a, st = oracle.auto_choose(h["hand"][k], last, h["left"][k].astype(np.int32), int(h["role"][k]), want_stats=True)
+        assert a == h["choice"][k] and st[0] == h["combinations"][k] and st[1] == h["nodes"][k], k
+
+
 def _brute_multisets(rows, target):
     """every multiset of rows summing to target, by brute force over multiplicities (tiny inputs only)"""
     out = set()
