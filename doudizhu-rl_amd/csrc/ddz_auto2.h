@@ -34,6 +34,7 @@ constexpr int A2_DEPTH = 20;      // actions below an item's root (a combination
 constexpr int A2_NOFROM = 1023;
 constexpr int A2_TICKET_SLOTS = 1024;  // ring of per-launch ticket words (ddz_engine.hip launch_auto)
 __device__ uint32_t g_tickets[A2_TICKET_SLOTS];
+__device__ int32_t g_device_status;  // status bits of the stateless entry points (ddz_device_status reads and clears it)
 #ifndef A2_SCAN_ROUNDS
 #define A2_SCAN_ROUNDS 1          // candidate-scan rounds (of four candidates) per search-loop trip
 #endif
@@ -68,7 +69,9 @@ struct A2Team {
   uint32_t finished;   // helpers whose result is written
   uint32_t pad;
   uint32_t flags;      // nosplit | follow << 1 | pass_ok << 2 | prune << 3
-  double thr;          // the best score any member has reached (pruning only: a stale value is a weaker bound)
+  uint64_t thr_bits;   // the best score any member has reached, as the bit pattern of the double: read and written with
+                       // 64-bit relaxed atomics only (a2_thr_load / a2_thr_store) -- pruning only, a stale value is a
+                       // weaker bound, a torn or compiler-cached one could be a wrong one
   uint64_t hand, bsw0, bsw1, bsw2, sm0, sm1;
   double rp;
   uint32_t esingle, epair;
@@ -80,6 +83,12 @@ struct A2Team {
 };
 __device__ __forceinline__ uint32_t a2_peek(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double a2_thr_load(const A2Team& t) {
+  return __longlong_as_double((long long)__hip_atomic_load(&t.thr_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void a2_thr_store(A2Team& t, double v) {
+  __hip_atomic_store(&t.thr_bits, (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the team's lock is taken by lane 0 for the whole wave (the other lanes wait at the reconvergence point).  Critical
 // sections are a few hundred cycles and every waiting loop peeks before it locks, so the spin is short; the bound is a
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       const uint32_t fl = TO.flags;
       q.nosplit = fl & 1u; q.follow = (fl >> 1) & 1u; q.pass_ok = (fl >> 2) & 1u; PRUNE = (fl >> 3) & 1u;
       bsw0 = TO.bsw0; bsw1 = TO.bsw1; bsw2 = TO.bsw2; sm0 = TO.sm0; sm1 = TO.sm1;
-      thr = TO.thr;
+      thr = a2_thr_load(TO);
     }
     // ---- 3. search: lanes take items from the end of the list and walk their subtrees; when the list is empty, idle
     // lanes take over ALL unexplored siblings of a busy lane's SHALLOWEST open level (every shallower level of that lane is
@@ -923,9 +932,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         const double bvw = wave_max_f64(best.move >= 0 ? best.value : -__builtin_inf());  // (values are never NaN)
         thr = bvw > thr ? bvw : thr;
         if (in_team) {
-          const double tt = TM.thr;
+          const double tt = a2_thr_load(TM);
           if (tt > thr) thr = tt;
-          else if (thr > tt && lane == 0) TM.thr = thr;
+          else if (thr > tt && lane == 0) a2_thr_store(TM, thr);
         }
       }
       if (a.teams && (in_team ? (trip & 1) == 0 : (trip & 3) == 0 && trip >= 8)) {
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           if (mine && lane == 0) {
             TM.owner = (uint32_t)wv; TM.active = 1; TM.box_n = 0; TM.hungry = 0; TM.members = 1; TM.finished = 0;
             TM.flags = (q.nosplit ? 1u : 0u) | (q.follow ? 2u : 0u) | (q.pass_ok ? 4u : 0u) | (PRUNE ? 8u : 0u);
-            TM.thr = thr; TM.hand = q.hand; TM.bsw0 = bsw0; TM.bsw1 = bsw1; TM.bsw2 = bsw2; TM.sm0 = sm0; TM.sm1 = sm1;
+            a2_thr_store(TM, thr); TM.hand = q.hand; TM.bsw0 = bsw0; TM.bsw1 = bsw1; TM.bsw2 = bsw2; TM.sm0 = sm0; TM.sm1 = sm1;
             TM.rp = q.rp; TM.esingle = q.esingle; TM.epair = q.epair;
             TM.open = 1;
           }

@@ -1967,7 +1967,7 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
                                                  const float4* __restrict__ w2, const float* __restrict__ b2,
                                                  const int32_t* __restrict__ counts, const uint4* __restrict__ rows, int64_t stride,
                                                  float* __restrict__ q, const int32_t* __restrict__ pidx, QRow0 row0,
-                                                 const float4* __restrict__ tab) {
+                                                 const float4* __restrict__ tab, int32_t* __restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
@@ -2013,9 +2013,13 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab(const float4* __restrict__ U, 
           if (PACKED) {
             // (a count the actor does not hold has no row: such a move is not legal -- read rank r's count-0 row instead
             // of faulting on a list that does not belong to this state)
+            // a row index at or beyond n_rows (a row_index that does not belong to this u: a stale pack, a caller's
+            // bug) is never dereferenced: count-0 row + status bit 5
             const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, qp_col(r, (int)c));
             z0 = ut[(row0.v[r] + t) * (QH / 4)];
-            v = pr >= 0 ? ut[(int64_t)pr * (QH / 4)] : z0;
+            const bool inside = (uint32_t)pr < (uint32_t)row0.v[15];
+            v = inside ? ut[(int64_t)pr * (QH / 4)] : z0;
+            if (pr >= 0 && !inside && lane == 0) atomicOr(status, 32);
           } else {
             v = ut[(r * 5 + (int64_t)c) * cstride]; z0 = ut[r * 5 * cstride];
           }
@@ -2104,10 +2108,13 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
         if (r < 13) pr4 = *(const int4*)&s_pidx[ti * QP_COLS + 4 * r];
         else pr4.x = s_pidx[ti * QP_COLS + 52 + (r - 13)];
         const uint32_t ys = (uint32_t)ystride;  // (rows x stride < 2^31: checked by the caller)
-        if (pr4.x >= 0) y[(uint32_t)pr4.x * ys + c] = fmaxf(fmaxf(s0 + a[0][0], s1 + a[0][1]), fmaxf(s2 + a[0][2], s3 + a[0][3]));
-        if (pr4.y >= 0) y[(uint32_t)pr4.y * ys + c] = fmaxf(fmaxf(s0 + a[1][0], s1 + a[1][1]), fmaxf(s2 + a[1][2], s3 + a[1][3]));
-        if (pr4.z >= 0) y[(uint32_t)pr4.z * ys + c] = fmaxf(fmaxf(s0 + a[2][0], s1 + a[2][1]), fmaxf(s2 + a[2][2], s3 + a[2][3]));
-        if (pr4.w >= 0) y[(uint32_t)pr4.w * ys + c] = fmaxf(fmaxf(s0 + a[3][0], s1 + a[3][1]), fmaxf(s2 + a[3][2], s3 + a[3][3]));
+        // (unsigned compares: -1 = not held and anything at or beyond n_rows -- a row_index that does not belong to this
+        // y -- are skipped alike, nothing outside y[:n_rows] is ever written)
+        const uint32_t nr = (uint32_t)row0.v[15];
+        if ((uint32_t)pr4.x < nr) y[(uint32_t)pr4.x * ys + c] = fmaxf(fmaxf(s0 + a[0][0], s1 + a[0][1]), fmaxf(s2 + a[0][2], s3 + a[0][3]));
+        if ((uint32_t)pr4.y < nr) y[(uint32_t)pr4.y * ys + c] = fmaxf(fmaxf(s0 + a[1][0], s1 + a[1][1]), fmaxf(s2 + a[1][2], s3 + a[1][3]));
+        if ((uint32_t)pr4.z < nr) y[(uint32_t)pr4.z * ys + c] = fmaxf(fmaxf(s0 + a[2][0], s1 + a[2][1]), fmaxf(s2 + a[2][2], s3 + a[2][3]));
+        if ((uint32_t)pr4.w < nr) y[(uint32_t)pr4.w * ys + c] = fmaxf(fmaxf(s0 + a[3][0], s1 + a[3][1]), fmaxf(s2 + a[3][2], s3 + a[3][3]));
       } else {
         for (int n = 0; n < ncnt; ++n)
           d[(n + 1) * cs] = fmaxf(fmaxf(s0 + a[n][0], s1 + a[n][1]), fmaxf(s2 + a[n][2], s3 + a[n][3]));
@@ -2329,6 +2336,7 @@ constexpr int MAX_DEVICES = 64;
 std::mutex g_table_mutex[MAX_DEVICES];
 std::atomic<bool> g_table_ready[MAX_DEVICES];
 extern uint32_t* g_ticket_base[MAX_DEVICES];
+extern int32_t* g_device_status_ptr[MAX_DEVICES];
 int build_table_locked(int device);
 int ensure_table(int device) {
   if (device < 0 || device >= MAX_DEVICES) return DDZ_ENODEV;
@@ -2345,6 +2353,10 @@ int build_table_locked(int device) {
     const hipError_t r0 = hipGetSymbolAddress(&tk, HIP_SYMBOL(g_tickets));
     if (r0 != hipSuccess) return hip_fail(r0);
     g_ticket_base[device] = (uint32_t*)tk;
+    void* ds = nullptr;
+    const hipError_t r1 = hipGetSymbolAddress(&ds, HIP_SYMBOL(g_device_status));
+    if (r1 != hipSuccess) return hip_fail(r1);
+    g_device_status_ptr[device] = (int32_t*)ds;
   }
   int32_t* flag = nullptr;
   hipError_t r = hipHostMalloc((void**)&flag, sizeof(int32_t), 0);  // host-pinned status word
@@ -2482,6 +2494,7 @@ static int auto_blocks(int device, int64_t n) {
 // per-device ring of device globals, zeroed on the launch stream right before the kernel: no re-arm protocol, nothing a
 // failed / rejected / concurrent launch (another stream of the same handle, the stateless entry point) can leave behind.
 std::atomic<uint32_t> g_ticket_next[MAX_DEVICES];
+int32_t* g_device_status_ptr[MAX_DEVICES];  // device address of g_device_status (the stateless entry points' status word)
 uint32_t* g_ticket_base[MAX_DEVICES];  // device address of g_tickets, resolved once per device (under the table mutex)
 constexpr int AUTO_K_SEQUENTIAL = 1, AUTO_K_LANES = 2, AUTO_K_LANES_TABLE_ORDER = 3;
 // the handle's form: heaviest hands first (k_auto_order into a slot of the handle's ring), then k_auto2 over that queue
@@ -3022,7 +3035,7 @@ int ddz_auto_choose(int device, const int8_t* hands, const int8_t* lasts, const 
   if (rc) return rc;
   AutoArgs a{};
   a.hands = (const uint4*)hands; a.lasts = (const uint4*)lasts; a.info = (const uint32_t*)info;
-  a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = nullptr; a.teams = 1;
+  a.T = n; a.tpw = 1; a.ids = ids; a.stats = stats; a.status = g_device_status_ptr[device]; a.teams = 1;
   fill_round_penalty(a);
   return launch_auto<false>(device, a, (hipStream_t)stream);
 }
@@ -3052,6 +3065,20 @@ int ddz_status(ddz_env_t* e, int32_t* out, void* stream) {
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
   hipError_t r = hipMemcpyAsync(out, e->sc.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (r != hipSuccess) return hip_fail(r);
+  r = hipStreamSynchronize((hipStream_t)stream);
+  return r == hipSuccess ? DDZ_OK : hip_fail(r);
+}
+
+int ddz_device_status(int device, int32_t* out, void* stream) {
+  if (!out) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  int rc = ensure_table(device);
+  if (rc) return rc;
+  hipError_t r = hipMemcpyAsync(out, g_device_status_ptr[device], 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (r != hipSuccess) return hip_fail(r);
+  r = hipMemsetAsync(g_device_status_ptr[device], 0, 4, (hipStream_t)stream);
   if (r != hipSuccess) return hip_fail(r);
   r = hipStreamSynchronize((hipStream_t)stream);
   return r == hipSuccess ? DDZ_OK : hip_fail(r);
@@ -3117,7 +3144,7 @@ int ddz_q_slab(ddz_env_t* e, const float* u, const float* z, int64_t hidden, con
   const int64_t per_block = (int64_t)WPB * tpw;
   hipLaunchKernelGGL(k_q_slab<false>, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
                      (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q,
-                     (const int32_t*)nullptr, QRow0{}, (const float4*)nullptr);
+                     (const int32_t*)nullptr, QRow0{}, (const float4*)nullptr, e->sc.status);
   return check_launch();
 }
 
@@ -3138,7 +3165,7 @@ int ddz_q_slab_packed(ddz_env_t* e, const float* u, const int32_t* row_index, co
   const int64_t per_block = (int64_t)WPB * tpw;
   hipLaunchKernelGGL(k_q_slab<true>, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
                      (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q,
-                     row_index, row0, (const float4*)table_term);
+                     row_index, row0, (const float4*)table_term, e->sc.status);
   return check_launch();
 }
 

@@ -180,7 +180,8 @@ class FactorisedQ:
         self.refresh()
 
     def _versions(self):
-        return tuple(p._version for p in self.net.parameters()) + (next(self.net.parameters()).device,)
+        # (id and storage address too: load_state_dict(assign=True) / a swapped Parameter can carry an equal version)
+        return tuple((id(p), p.data_ptr(), p._version) for p in self.net.parameters()) + (next(self.net.parameters()).device,)
 
     @torch.no_grad()
     def refresh(self):
@@ -315,7 +316,10 @@ class FactorisedQ:
         """face f32 [T,P,15,4], hands int [T,15] -> PackedU: the rows of tables() a legal move can use (a third of them
         at ~10 cards per hand: a third of the fc1 GEMM and of the first layer's stores), one GEMM per rank over that rank's
         rows (or one batched GEMM over padded segments: batched_gemm), the per-table term on its own.  One host sync (pack).  fused=False (CPU): the same rows
-        gathered from the plain-torch tables() -- the statement the packed kernels are tested against."""
+        gathered from the plain-torch tables() -- the statement the packed kernels are tested against.
+        The result's .u is THIS object's cached workspace, not a copy: the next tables_packed() call on the same
+        FactorisedQ overwrites it (and a batch holding more cards than any before reallocates it) -- consume a PackedU
+        before asking for the next one, or clone .u."""
         if self._ver != self._versions():
             self.refresh()
         T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
@@ -323,6 +327,9 @@ class FactorisedQ:
             raise ValueError(f"face must be [T,{P},15,4] and hands [T,15]")
         if fused is None:
             fused = face.is_cuda
+        if T * 69 * max(H, H1) >= 1 << 31:
+            raise ValueError(f"tables_packed: {T} tables can need more packed rows than ddz_q_features_packed indexes with 32 "
+                             "bits; call it on slices of at most 120,000 tables (tables() chunks by itself)")
         row_index, row0 = self.pack(hands)
         n = row0[15]
         key = ("packed", face.device)

@@ -648,6 +648,16 @@ def auto_choose(hands, lasts, left, role, want_stats=False):
     return (ids, stats) if want_stats else ids
 
 
+def device_status(device="cuda:0"):
+    """Status bits of the stateless rule-agent launches on this device since the last call (ddz_device_status; bit 3 = a
+    cooperating wait hit its hang guard: do not trust those ids); host sync, clears the word."""
+    L = _lib.lib()
+    dev = _require_gpu(device)
+    out = C.c_int32(0)
+    check(L.ddz_device_status(dev.index, C.byref(out), _stream(dev)))
+    return out.value
+
+
 def cards_value(device="cuda:0"):
     """cards_value of rule_based/utils/evaluator.py:10-47 for every action id, float64 [13527] (device test hook)."""
     L = _lib.lib()

@@ -29,7 +29,15 @@ class Env:
         self._seed = int(seed) if seed else random.getrandbits(63)
         self._b = BatchedEnv(1, seed=self._seed, device=self.device)
         self._sel = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._nlegal = None
+        self._sel_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._row_host = torch.zeros((1, 16), dtype=torch.int8).pin_memory()
+        self._row = torch.zeros((1, 16), dtype=torch.int8, device=self.device)
+        # host mirror of the table, refreshed by ONE synchronisation per ply: the 176-byte state and the size of the new
+        # legal list land in pinned memory behind the launch that produced them (ddz_step_slab applies the move AND
+        # writes the next state's list)
+        self._h_state = torch.zeros(176, dtype=torch.uint8).pin_memory()
+        self._h_count = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._nlegal = 0
         self.debug = debug
         self._clear()
 
@@ -42,7 +50,11 @@ class Env:
         self.old_cards = dict()
 
     def _sync(self):
-        s = self._b.state.view(11, 16).cpu().numpy()
+        self._h_state.copy_(self._b.state, non_blocking=True)
+        self._h_count.copy_(self._b.counts, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()      # the one device -> host round trip of a ply
+        self._nlegal = int(self._h_count[0])
+        s = self._h_state.numpy().reshape(11, 16)
         self.taken = s[F_TAKEN, :15].astype(float)
         self.left = s[F_HAND0:F_HAND0 + 3, 15].astype(int)
         for r in range(3):
@@ -58,7 +70,7 @@ class Env:
     def prepare(self):
         """native shuffle + deal + lord selection (game.py:171); deal = spec v2."""
         self._b.reset()
-        self._nlegal = None
+        self._b.legal_slab()
         self._sync()
 
     # ---- native getters used by the callers (SURVEY.md 8b) ----
@@ -96,13 +108,12 @@ class Env:
         return int(self._meta[4]) | (int(self._meta[5]) << 8)
 
     def _step(self, sel, mode):
-        """one engine step + ONE device -> host copy (the 176-byte state): done / r are the meta row's, an action that
-        was not in the legal list leaves the table untouched (same ply counter)"""
+        """one launch (apply + the next state's legal list) + ONE device -> host round trip (_sync): done / r are the
+        meta row's, an action that was not in the legal list leaves the table untouched (same ply counter)"""
         if self._meta[1]:  # a finished table stays as it is (no auto-reset in this view)
             return 0, True
         before = self._ply()
-        self._nlegal = None
-        self._b.step(sel, mode, auto_reset=False)
+        self._b.step_slab(sel, mode, auto_reset=False)
         self._sync()
         if self._ply() == before:
             raise ValueError("illegal action for the current state")
@@ -112,7 +123,8 @@ class Env:
     def _apply(self, idx):
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        self._sel.fill_(int(idx))
+        self._sel_host[0] = int(idx)
+        self._sel.copy_(self._sel_host, non_blocking=True)
         r, done = self._step(self._sel, STEP_CHOICE)
         res = (r, done, None)
         if self.debug:
@@ -125,9 +137,13 @@ class Env:
         against the legal list itself (DDZ_STEP_ROWS)."""
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        row = np.zeros((1, 16), np.int8)
-        row[0, :15] = np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8)
-        r, done = self._step(torch.from_numpy(row), STEP_ROWS)
+        if torch.is_tensor(onehot_cards) and onehot_cards.is_cuda:
+            # decoded on the device (the row sum of onehot2arr, envi.py:148-157): no device -> host copy of the action
+            self._row[0, :15] = onehot_cards.reshape(15, 4).sum(dim=1).round().to(torch.int8)
+        else:
+            self._row_host[0, :15] = torch.from_numpy(np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8))
+            self._row.copy_(self._row_host, non_blocking=True)
+        r, done = self._step(self._row, STEP_ROWS)
         if self.debug:
             print('role {} plays {}, left {}'.format(
                 role, self.cards2str(self.arr2cards(self.recent_handout[role].astype(int))), self.left))
@@ -145,10 +161,8 @@ class Env:
         return cards, r, None
 
     def _legal(self):
-        """(rows, n) of the current state; the list size crosses to the host once per state"""
-        if self._nlegal is None or not self._b._legal_fresh:
-            offsets, rows, _ = self._b.legal()
-            self._nlegal = int(offsets[1].item())
+        """(rows, n) of the current state: the list the last launch left in the table's slab, its size from the host
+        mirror (no device round trip)"""
         return self._b.rows, self._nlegal
 
     def step_random(self):

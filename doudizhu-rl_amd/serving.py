@@ -1,4 +1,5 @@
-"""Stateless observation / legal moves from the reference's serving payload.
+"""Stateless observation / legal moves from the reference's serving payload, and the payloads of live tables
+(state_to_payloads <-> payloads_to_state).
 
 The reference's HTTP predictor receives, per request, a dict
     {role_id, cur_cards, history{0,1,2}, left{0,1,2}, last_taken{0,1,2}}      (server/client.py:6-25)
@@ -42,6 +43,32 @@ def payloads_to_state(payloads):
         st[i, F_META, 2] = 0xFF
         st[i, F_META, 6] = 1
     return st
+
+
+def state_to_payloads(state):
+    """The inverse of payloads_to_state: state rows (uint8 [n,11,16] -- a numpy array, a tensor, or a BatchedEnv, whose
+    state is copied to the host) -> the list of n serving payloads {role_id, cur_cards, history, left, last_taken} the
+    reference's HTTP predictor takes (server/client.py:6-25: card lists as rank values 3..17, dicts keyed by role 0 up /
+    1 lord / 2 down), one per table, as seen by the table's ACTOR (only its own hand is in a payload).  What a caller
+    that plays on the batched engine POSTs to a reference-style server."""
+    if isinstance(state, BatchedEnv):
+        state = state.state
+    if torch.is_tensor(state):
+        state = state.detach().cpu().numpy()
+    st = np.asarray(state, np.uint8).reshape(-1, NFIELDS, ROW)
+    ranks = np.arange(3, 18)
+
+    def cards(row):
+        return [int(x) for x in np.repeat(ranks, row[:15].astype(int))]   # envi.py:118-130 arr2cards
+
+    out = []
+    for s in st:
+        role = int(s[F_META, 0])
+        out.append({"role_id": role, "cur_cards": cards(s[F_HAND0 + role]),
+                    "history": {r: cards(s[F_HIST0 + r]) for r in range(3)},
+                    "left": {r: int(s[F_HAND0 + r, 15]) for r in range(3)},
+                    "last_taken": {r: cards(s[F_RECENT0 + r]) for r in range(3)}})
+    return out
 
 
 class BatchedPredictorInputs:

@@ -268,7 +268,9 @@ int ddz_q_slab(ddz_env_t* env, const float* u, const float* z, int64_t hidden, c
  *   segment are count 0 of tables 0..T-1, then the held counts in any order;
  *   row_index int32 [T][64] (device): row of (r < 13, c = 1..4) at column 4 r + c - 1, of a joker's count 1 at column 52 /
  *   53; -1 = not held (ddz_q_features_packed skips it; ddz_q_slab_packed reads the count-0 row instead: no legal move of
- *   the table takes that count).
+ *   the table takes that count).  Entries are device data and are never trusted as addresses: one at or beyond n_rows is
+ *   treated like -1 by both functions (nothing outside y[:n_rows] / u[:n_rows] is touched) and ddz_q_slab_packed raises
+ *   status bit 5.
  * y / u f32 [n_rows][y_row_stride / hidden]; the glue multiplies each rank's rows by that rank's fc1 block (15 GEMMs).
  * table_term f32 [T][hidden] or NULL: the per-table term (fc1 bias + the face part of conv_shunzi), added once per table
  * (the unpacked form carries it on rank 0's rows).  Results equal the unpacked functions' up to the GEMM's summation order. */
@@ -334,9 +336,15 @@ int ddz_debug_set_auto_teams(ddz_env_t* env, int on);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
  * bit2 invalid `last` combo, bit3 a wait of ddz_auto_choose_state's cooperating wavefronts hit its
- * hang guard (never in a working launch; the ids of that launch are not to be trusted).
+ * hang guard (never in a working launch; the ids of that launch are not to be trusted), bit4 the sequential
+ * cross-check kernel's depth guard (cannot happen: at most 20 actions), bit5 a row_index entry of ddz_q_slab_packed at or
+ * beyond n_rows (not dereferenced: the count-0 row was read instead).
  * Copies 4 bytes D2H on `stream` and synchronises it.                                   */
 int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);
+/* the same word for the STATELESS rule-agent entry point (ddz_auto_choose has no handle): one per device, bits as above
+ * (bit 3: a cooperating wait hit its hang guard -- the ids of launches since the last call are not to be trusted).
+ * Copies 4 bytes D2H on `stream`, clears the word, synchronises.                                                  */
+int ddz_device_status(int device_id, int32_t* status_out, void* stream);
 
 /* test hook: CardGroup.to_cardgroup (card.py:327-335) of arbitrary count rows int8[n][16] ->
  * out u32[n] = category | value << 8 | len << 16, or 0xFF when the row is no combo.       */

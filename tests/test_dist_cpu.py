@@ -88,6 +88,56 @@ def test_gather_trajectories_world2_matches_single_process():
             assert to0 is None
 
 
+BIG_BASE = (1 << 32) + 12345   # global table ids beyond 32 bits: the RNG counter takes both halves
+
+
+def _worker8(rank, world, port, q, total, base0):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ddist = importlib.import_module("doudizhu-rl_amd.dist")
+        n, base = ddist.shard_tables(total, rank, world)
+        local = torch.from_numpy(_rollout(n, base0 + base, seed=7))
+        to0 = ddist.gather_trajectories(local, dst=0)                       # the bench's exchange: gather to the learner
+        sizes = [ddist.shard_tables(total, r, world)[0] for r in range(world)]
+        to0b = ddist.gather_trajectories(local, dst=0, shard_sizes=sizes)   # ... with the sizes known (no size exchange)
+        allr = ddist.gather_trajectories(local)                             # all_gather form
+        ok = (to0 is None) == (rank != 0) and (to0b is None) == (rank != 0)
+        if rank == 0:
+            ok = ok and torch.equal(to0, to0b) and torch.equal(to0, allr)
+        x = allr.contiguous().view(torch.int64).view(-1)
+        digest = int((x * 31 + (x >> 13) + torch.arange(x.numel()) * x).sum().item())     # bench.py's digest
+        q.put((rank, n, base, ok, digest, allr.numpy() if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_trajectories_world8_ragged_ids_beyond_32_bits():
+    """configs[4]'s id arithmetic at eight ranks (gloo, CPU): 8 ragged shards (61 tables -> 8,8,8,8,8,7,7,7) of a batch
+    whose global table ids start beyond 2^32; gather to rank 0 (with and without known sizes) and all_gather give the
+    single-process rollout of the union, same digest on every rank.  (524,288 tables -> 65,536 per rank, bases r * 65,536:
+    test_shard_tables_partition.)"""
+    world, total = 8, 61
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, total, BIG_BASE)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [8, 8, 8, 8, 8, 7, 7, 7] and [r[2] for r in res] == [0, 8, 16, 24, 32, 40, 47, 54]
+    assert all(r[3] for r in res)
+    single = _rollout(total, BIG_BASE, seed=7)
+    assert np.array_equal(res[0][5], single)
+    x = torch.from_numpy(single).contiguous().view(torch.int64).view(-1)
+    want = int((x * 31 + (x >> 13) + torch.arange(x.numel()) * x).sum().item())
+    assert all(r[4] == want for r in res)
+    assert not np.array_equal(single, _rollout(total, 12345, seed=7))       # the high half of the id reaches the RNG
+
+
 def test_unpack_trajectory_fields():
     ddist = importlib.import_module("doudizhu-rl_amd.dist")
     traj = torch.from_numpy(_rollout(8, 0, seed=5))

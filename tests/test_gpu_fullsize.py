@@ -227,6 +227,25 @@ def test_packed_q_entry_points_reject_a_layout_that_does_not_fit_the_tables(pkg)
     valid = torch.arange(env.slab_stride, device=_dev())[None, :] < counts[:, None]
     assert bool(torch.isfinite(q0[valid]).all()) and bool(torch.isfinite(q[valid]).all())
     assert env.status() == 0
+    # row_index is DEVICE data and is never trusted as an address: entries at or beyond n_rows (a stale pack, a row_index
+    # of other hands) are skipped by ddz_q_features_packed -- nothing outside y[:n_rows] changes, nothing inside either
+    # where no valid row points -- and read as the count-0 row by ddz_q_slab_packed, which raises status bit 5
+    n_rows = good[15]
+    wild = pu.row_index.clone()
+    held = wild >= 0
+    wild[held] = wild[held] + n_rows                                     # every held row now points beyond the buffer
+    wild[0, 0] = 0x7FFFFFF0
+    y = torch.full((n_rows + 4096, 256), 7.0, device=_dev())
+    pkg.q_features_packed(face, fq.Wf, fq.bias_f, fq.A, wild, good, y)
+    torch.cuda.synchronize()
+    written = (y != 7.0).any(1)
+    count0 = torch.zeros(n_rows + 4096, dtype=torch.bool, device=_dev())
+    for r in range(15):
+        count0[good[r]: good[r] + T] = True                              # the T count-0 rows of every rank: always written
+    assert bool((written == count0).all())
+    qw = env.q_slab_packed(pu.u, wild, good, pu.table_term, fq.Z, fq.w2, fq.b2)
+    assert torch.equal(qw[valid], q0[valid])                             # exactly the all-held-columns-absent result
+    assert env.status() & 32
 
 
 def test_policy_loop_with_the_q_network_full_size_with_oracle_slice(pkg, oracle):

@@ -528,15 +528,19 @@ def test_serving_payload_inputs(pkg, oracle):
     for _ in range(31):
         ref.legal(); ref.step(oracle.STEP_RANDOM)
     roff, rrows, _ = ref.legal()
-    cards = lambda row: [int(x) for x in np.repeat(np.arange(3, 18), row[:15].astype(int))]
-    payloads = []
-    for t in range(T):
-        role = int(ref.field(10)[t, 0])
-        payloads.append(json.loads(json.dumps({                      # through JSON like the HTTP service
-            "role_id": role, "cur_cards": cards(ref.field(role)[t]),
-            "history": {r: cards(ref.field(3 + r)[t]) for r in range(3)},
-            "left": {r: int(ref.field(r)[t, 15]) for r in range(3)},
-            "last_taken": {r: cards(ref.field(6 + r)[t]) for r in range(3)}})))
+    # the exporter (state -> payloads, server/client.py:6-25), through JSON like the HTTP service
+    payloads = json.loads(json.dumps(serving.state_to_payloads(ref.state)))
+    t = 7
+    role = int(ref.field(10)[t, 0])
+    assert payloads[t]["role_id"] == role and len(payloads[t]["cur_cards"]) == int(ref.field(role)[t, 15])
+    assert payloads[t]["cur_cards"] == [int(x) for x in np.repeat(np.arange(3, 18), ref.field(role)[t, :15].astype(int))]
+    assert [payloads[t]["left"][str(r)] for r in range(3)] == [int(ref.field(r)[t, 15]) for r in range(3)]
+    # and back: only the actor's hand travels, everything `face` and the legal moves read is there
+    back = serving.payloads_to_state(payloads)
+    full = ref.state.reshape(T, 11, 16)
+    for tt in range(T):
+        rr = int(full[tt, 10, 0])
+        assert np.array_equal(back[tt, rr], full[tt, rr]) and np.array_equal(back[tt, 3:10, :15], full[tt, 3:10, :15])
     pred = serving.BatchedPredictorInputs()
     face = pred.face(payloads).cpu().numpy()
     assert np.array_equal(face.view(np.uint32), ref.observe(3).view(np.uint32))
