@@ -4,11 +4,15 @@
   python bench.py --gpus N --steps K --warmup W
 A "step" is one lock-step iteration of the hot path over all tables of this rank: legal-move enumeration into the
 per-table list + random-policy action application with auto-reset (game.py:169-181 with envi.py:79-116).
-  N = 1: BASELINE.json configs[1], 4096 tables on one MI355X, random policy, legal-move list only.
-  N > 1: 65,536 tables per GPU (configs[4] = 524,288 tables at N = 8), weak scaling: every GPU owns a range of the
-         global table ids and the timed region is the same at every N (tables are independent: no data-path
-         collective).  The path's one exchange -- packed trajectories gathered to rank 0 over RCCL -- is measured
-         right after the headline region (config.exchange, env_steps_per_s_with_gather).
+  Every N: 65,536 tables per GPU -- the largest single-GPU table count of BASELINE.json (configs[2], configs[3]; configs[4]
+         = 524,288 tables at N = 8), random policy, legal-move list only (the workload of configs[1]).  Weak scaling: every
+         GPU owns a range of the global table ids and the timed region is the same at every N (tables are independent: no
+         data-path collective); the N = 1 line is the N > 1 line's per-GPU workload.  The path's one exchange -- packed
+         trajectories gathered to rank 0 over RCCL -- is measured right after the headline region (config.exchange,
+         env_steps_per_s_with_gather, the ranks' own rates and the gather on its own).
+  N = 1 also carries measured legs of the other single-GPU configurations (`configs`), each with the roofline that
+         bounds its dominant kernel: configs[1] as written (4096 tables), the policy-driven stepping launch, configs[2]
+         with the Q-network in the loop, configs[3] against the rule agent, the CSR layout beside the slab layout.
 The K-iteration launch is repeated until at least 50 ms have been timed, whatever K is (a single short launch
 would measure launch latency); `value` and `ms_per_step` are means over all timed iterations.  Rank 0 prints ONE
 JSON line; at N = 1 it also carries short measured legs of the other single-GPU configs (`configs`).
@@ -25,6 +29,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, exact f32, 64 FLOP/clk/SIMD (= the f32 vector peak)
+T_FULL = 65536          # tables per GPU: the largest single-GPU configuration of BASELINE.json
 MIN_TIMED_S = 0.05      # every timed region covers at least this much GPU time
 
 
@@ -169,64 +175,201 @@ def timed_loop(fn, sync, min_s=MIN_TIMED_S, max_reps=1 << 16):
     return time.perf_counter() - t0, reps
 
 
-def other_config_legs(pkg, torch, dev):
-    """Short measured legs of the other single-GPU configurations of BASELINE.json (numbers, not prose)."""
-    out = {}
-    T = 65536
+def rollout_leg(pkg, torch, dev, T, pmc_key):
+    """The headline loop at another table count (configs[1] as BASELINE.json writes it: 4096 tables): rate by wall clock
+    between syncs, k_rollout's launch duration by HIP events, the roofline block, and the packed-CSR form of the loop."""
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    env = pkg.BatchedEnv(T, seed=0, device=dev, want_ids=False)
+    env.reset()
+    env.rollout_random(200)
+    k = 1000
+    dt, reps = timed_loop(lambda: env.rollout_random(k), sync)
+    sa = env.stats()
+    ms, n = 0.0, 0
+    while ms < MIN_TIMED_S * 1e3 and n < 4096:
+        ms += env.rollout_random_timed(k)
+        n += 1
+    sb = env.stats()
+    steps = sb["plies"] - sa["plies"]
+    mean_a = (sb["legal_rows"] - sa["legal_rows"]) / max(1, steps)
+    dur = ms * 1e-3 / n
+    out = {"env_steps_per_s": T * k * reps / dt, "us_per_iteration": dt / (k * reps) * 1e6, "iterations": k * reps,
+           "mean_legal_moves": mean_a,
+           "roofline": hbm_block("k_rollout", (260 + 16 * mean_a) * steps / n, dur, launches_timed=n,
+                                 env_steps_per_launch=steps / n, algorithmic_bytes_per_env_step=260 + 16 * mean_a,
+                                 issue=issue_block(pmc_key, steps / n, dur))}
+    env.rollout_random_csr(20)
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(50), sync)
+    out["csr_env_steps_per_s"] = T * 50 * repc / dtc
+    out["csr_us_per_iteration"] = dtc / (50 * repc) * 1e6
+    assert env.status() == 0
+    return out
+
+
+def other_config_legs(pkg, torch, dev, errors):
+    """Measured legs of the other single-GPU configurations of BASELINE.json (numbers, not prose), each with the roofline
+    of its dominant kernel.  A leg that raises lands in `errors` (the run then exits non-zero) and the others still run."""
+    out = {}
+    T = T_FULL
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as ex:  # noqa: BLE001
+            errors.append({"leg": name, "error": repr(ex)[:300]})
+            out[name] = {"error": repr(ex)[:300]}
+            print(f"[bench] leg {name} FAILED: {ex!r}", file=sys.stderr, flush=True)
+
+    # (0) configs[1] exactly as BASELINE.json writes it: 4096 tables, random policy, legal-move list only
+    leg("tables_4096_random_rollout", lambda: rollout_leg(pkg, torch, dev, 4096, "k_rollout"))
     env = pkg.BatchedEnv(T, seed=0, device=dev)
     env.reset()
     env.rollout_random(200)
-    # (1) the random-policy rollout of the headline at 65,536 tables
-    k = 500
-    dt, reps = timed_loop(lambda: env.rollout_random(k), sync)
-    out["tables_65536_random_rollout"] = {"env_steps_per_s": T * k * reps / dt, "iterations": k * reps,
-                                          "us_per_iteration": dt / (k * reps) * 1e6}
-    # (1b) configs[4]'s per-rank half of the trajectory exchange (what every rank does before the gather over xGMI):
-    # the same rollout writing a 32-byte record per ply and table, then ddz_pack_trajectory to 8-byte records
-    kx = 100
-    traj = torch.zeros((kx, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
-    packed = [None]
 
-    def traj_iter():
-        env.rollout_random(kx, traj=traj)
-        packed[0] = pkg.pack_trajectory(traj)
+    # (1) configs[4]'s per-rank half of the trajectory exchange (what every rank does before the gather over xGMI):
+    # the rollout writing a 32-byte record per ply and table, then ddz_pack_trajectory to 8-byte records
+    def traj_leg():
+        kx = 100
+        traj = torch.zeros((kx, T, pkg.TRAJ_BYTES), dtype=torch.uint8, device=dev)
 
-    dt, reps = timed_loop(traj_iter, sync)
-    dtp, repp = timed_loop(lambda: pkg.pack_trajectory(traj), sync)
-    out["tables_65536_traj_write_pack"] = {
-        "env_steps_per_s": T * kx * reps / dt, "us_per_iteration": dt / (kx * reps) * 1e6, "iterations": kx * reps,
-        "pack_us_per_iteration": dtp / (kx * repp) * 1e6, "packed_bytes_per_iteration": T * pkg.TRAJ_PACKED_BYTES,
-        "packed_GBps_to_send": T * pkg.TRAJ_PACKED_BYTES * kx * reps / dt / 1e9,
-        "loop": "rollout_random(traj = 32-byte records) + pack_trajectory (8-byte records): the per-rank cost of "
-                "config 5 before the RCCL gather"}
-    del traj, packed
+        def traj_iter():
+            env.rollout_random(kx, traj=traj)
+            pkg.pack_trajectory(traj)
+
+        dt, reps = timed_loop(traj_iter, sync)
+        dtp, repp = timed_loop(lambda: pkg.pack_trajectory(traj), sync)
+        nrec = kx * T
+        return {"env_steps_per_s": T * kx * reps / dt, "us_per_iteration": dt / (kx * reps) * 1e6, "iterations": kx * reps,
+                "pack_us_per_iteration": dtp / (kx * repp) * 1e6, "packed_bytes_per_iteration": T * pkg.TRAJ_PACKED_BYTES,
+                "packed_GBps_to_send": T * pkg.TRAJ_PACKED_BYTES * kx * reps / dt / 1e9,
+                "roofline": hbm_block("k_pack_traj", nrec * (pkg.TRAJ_BYTES + pkg.TRAJ_PACKED_BYTES), dtp / repp,
+                                      algorithmic_bytes_per_record=pkg.TRAJ_BYTES + pkg.TRAJ_PACKED_BYTES),
+                "loop": "rollout_random(traj = 32-byte records) + pack_trajectory (8-byte records): the per-rank cost of "
+                        "config 5 before the RCCL gather"}
+
+    leg("tables_65536_traj_write_pack", traj_leg)
     # (2) configs[2]'s environment side: the loop a policy drives through the slab API -- face, selection over
     # per-action values, apply + next lists; one launch each (game.py:95-104, dqn.py:50-71).  The Q values are random
-    # numbers standing in for the network's output (the network itself is out of scope: SURVEY 2 #8).
+    # numbers standing in for the network's output (the network in the loop: tables_65536_dqn_inference).
     env.legal_slab()
     face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device=dev)
     q = torch.rand((T, env.slab_stride), dtype=torch.float32, device=dev)
     choice = torch.empty(T, dtype=torch.int32, device=dev)
 
-    def policy_iter():
-        env.observe(3, out=face)
-        env.select_slab(q, out=choice)
-        env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+    def mean_moves(fn):
+        s0 = env.stats()
+        r = fn()
+        s1 = env.stats()
+        return r, (s1["legal_rows"] - s0["legal_rows"]) / max(1, s1["plies"] - s0["plies"])
 
-    dt, reps = timed_loop(lambda: [policy_iter() for _ in range(20)], sync)
-    out["tables_65536_policy_loop_slab"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
-                                            "us_per_iteration": dt / (20 * reps) * 1e6,
-                                            "loop": "observe(EnvCooperationSimplify) + select_slab(random q) + step_slab(CHOICE)"}
-    # the same iteration in ONE launch: arg-max over q, apply, new lists and the new `face` (ddz_policy_step_slab)
-    dt, reps = timed_loop(lambda: [env.policy_step_slab(q, 0.0, face_variant=3, face_out=face) for _ in range(20)], sync)
-    out["tables_65536_policy_loop_fused"] = {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps,
-                                             "us_per_iteration": dt / (20 * reps) * 1e6,
-                                             "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
-    # configs[2] as SURVEY 8(d) defines it: EnvCooperationSimplify planes + NetCooperationSimplify (net.py:137-150)
-    # randomly initialised (torch.manual_seed(0)), eval mode, greedy arg-max per table over its legal list -- the
-    # network IN the loop (dqn_glue.PolicyLoop: per-rank GEMMs over the rows the actors' hands allow -> ddz_q_slab_packed ->
-    # ddz_policy_step_slab)
+    def policy_slab_leg():
+        def policy_iter():
+            env.observe(3, out=face)
+            env.select_slab(q, out=choice)
+            env.step_slab(choice, pkg.STEP_CHOICE, auto_reset=True)
+
+        (dt, reps), a = mean_moves(lambda: timed_loop(lambda: [policy_iter() for _ in range(20)], sync))
+        # bytes per table-step of the three launches: state 176 read x 3 + 176 written, face 1,440 written, q 4 A read,
+        # lists 20 A (+ 4) written, choice 4 + 4
+        b = 4 * 176 + 1440 + 24 * a + 12
+        return {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps, "us_per_iteration": dt / (20 * reps) * 1e6,
+                "mean_legal_moves": a, "roofline": hbm_block("k_observe<3> + k_select + k_slab<1,true>", b * T, dt / (20 * reps),
+                                                            algorithmic_bytes_per_table_step=b),
+                "loop": "observe(EnvCooperationSimplify) + select_slab(random q) + step_slab(CHOICE)"}
+
+    leg("tables_65536_policy_loop_slab", policy_slab_leg)
+
+    def policy_fused_leg():
+        # the same iteration in ONE launch: arg-max over q, apply, new lists and the new `face` (ddz_policy_step_slab)
+        (dt, reps), a = mean_moves(lambda: timed_loop(
+            lambda: [env.policy_step_slab(q, 0.0, face_variant=3, face_out=face) for _ in range(20)], sync))
+        b = 2 * 176 + 1440 + 24 * a + 8
+        return {"env_steps_per_s": T * 20 * reps / dt, "iterations": 20 * reps, "us_per_iteration": dt / (20 * reps) * 1e6,
+                "mean_legal_moves": a,
+                "roofline": hbm_block("k_slab<4,true>", b * T, dt / (20 * reps), algorithmic_bytes_per_table_step=b,
+                                      issue=issue_block("k_slab_fused_65536", T, dt / (20 * reps))),
+                "loop": "policy_step_slab(random q, face = EnvCooperationSimplify): one launch"}
+
+    leg("tables_65536_policy_loop_fused", policy_fused_leg)
+    leg("tables_65536_dqn_inference", lambda: dqn_leg(pkg, torch, dev, env))
+
+    # the stepping launch alone (uniformly random legal moves drawn in the kernel: every selection is in its list), and
+    # the same with the new lists packed to CSR every iteration (what a ragged NN forward over all legal moves consumes)
+    def step_slab_leg():
+        (dt, reps), a = mean_moves(lambda: timed_loop(
+            lambda: [env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True) for _ in range(20)], sync))
+        b = 260 + 20 * a       # SURVEY 8(d): 128 + 128 + 4 + 16 A, + 4 A for the ids this handle also writes
+        per = dt / (20 * reps)
+        return {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": per * 1e6, "mean_legal_moves": a,
+                "roofline": hbm_block("k_slab<0,true>", b * T, per, algorithmic_bytes_per_env_step=b,
+                                      issue=issue_block("k_slab_random_65536", T, per)),
+                "loop": "step_slab(RANDOM)"}
+
+    leg("tables_65536_step_slab_only", step_slab_leg)
+
+    def step_csr_leg():
+        def csr_iter():
+            env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
+            env.slab_to_csr(rows_per_table=128)
+
+        (dt, reps), a = mean_moves(lambda: timed_loop(lambda: [csr_iter() for _ in range(20)], sync))
+        dtc, repc = timed_loop(lambda: [env.slab_to_csr(rows_per_table=128) for _ in range(20)], sync)
+        env.csr_rows = env.csr_ids = None
+        env._csr_cap = 0
+        return {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6, "mean_legal_moves": a,
+                "slab_to_csr_us": dtc / (20 * repc) * 1e6,
+                "roofline": hbm_block("k_csr_scan + k_csr_copy", (8 + 40 * a) * T, dtc / (20 * repc),
+                                      algorithmic_bytes_per_table=8 + 40 * a,
+                                      note="the compaction pass alone: list sizes in, offsets out, 20-byte rows + ids read and written"),
+                "loop": "step_slab(RANDOM) + slab_to_csr: offsets / rows / ids as ddz_legal writes them"}
+
+    leg("tables_65536_step_slab_csr_lists", step_csr_leg)
+
+    # (3) configs[3]: farmers played by the rule-based opponent (Env.step_auto), the lord by the random policy
+    def rule_leg():
+        def auto_iter():
+            ids = env.auto_choose(0b101)
+            env.step_slab(ids, pkg.STEP_IDS, auto_reset=True)
+
+        env.reset()           # whole episodes against the rule agent: start from fresh deals and play past the first
+        env.legal_slab()      # games (a rule-agent game lasts ~25 plies) before episodes are counted
+        for _ in range(40):
+            auto_iter()
+        s0 = env.stats()
+        dt, reps = timed_loop(lambda: [auto_iter() for _ in range(5)], sync, min_s=0.2, max_reps=40)
+        s1 = env.stats()
+        dta, repa = timed_loop(lambda: env.auto_choose(0b101), sync, min_s=0.05, max_reps=200)   # the decisions alone
+        eps = max(1, s1["episodes"] - s0["episodes"])
+        lord, farm = s1["lord_wins"] - s0["lord_wins"], (s1["up_wins"] - s0["up_wins"]) + (s1["down_wins"] - s0["down_wins"])
+        role = env.role
+        n_dec = int(((role == 0) | (role == 2)).sum().item())
+        return {"env_steps_per_s": T * 5 * reps / dt, "us_per_iteration": dt / (5 * reps) * 1e6,
+                "us_auto_choose": dta / repa * 1e6, "decisions_per_launch": n_dec,
+                "mean_episode_return": {"lord": 100.0 * (lord - farm) / eps, "up": 50.0 * (farm - lord) / eps,
+                                        "down": 50.0 * (farm - lord) / eps},
+                "episodes": eps,
+                "roofline": hbm_block("k_auto2<true> (+ k_auto_order)", (176 + 4) * T, dta / repa,
+                                      algorithmic_bytes_per_table=180,
+                                      note="a search kernel: 176-byte state in, one id out -- the HBM roof says nothing here; "
+                                           "the bound is instruction issue (issue) and, per launch, its single longest decision",
+                                      issue=issue_block("k_auto2_65536", 1, dta / repa)),
+                "loop": "auto_choose(farmers) + step_slab(IDS), lord = engine RNG; reward_dict of game.py:13-14"}
+
+    leg("tables_65536_rule_opponent", rule_leg)
+    if env.status() != 0:
+        errors.append({"leg": "configs", "error": f"device status {env.status()}"})
+    del env, q, face
+    return out
+
+
+def dqn_leg(pkg, torch, dev, env):
+    """configs[2] as SURVEY 8(d) defines it: EnvCooperationSimplify planes + NetCooperationSimplify (net.py:137-150)
+    randomly initialised (torch.manual_seed(0)), eval mode, greedy arg-max per table over its legal list -- the network
+    IN the loop (dqn_glue.PolicyLoop).  Per-stage times by HIP events on the launching stream, a roofline per stage and
+    end to end."""
+    T = env.T
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
     torch.manual_seed(0)
     net = glue.QNet(6).to(dev).eval()
@@ -235,110 +378,101 @@ def other_config_legs(pkg, torch, dev):
     s0 = env.stats()
     dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.3, max_reps=64)
     s1 = env.stats()
-    dtn, repn = timed_loop(lambda: [loop.q_values() for _ in range(5)], sync, min_s=0.15, max_reps=64)
-    dtt, rept = timed_loop(lambda: [loop.fq.tables_packed(loop.face, env.actor_hands()) for _ in range(5)], sync,
-                           min_s=0.15, max_reps=64)
-    dte, repe = timed_loop(lambda: [env.policy_step_slab(loop.q, 0.0, face_variant=3, face_out=loop.face) for _ in range(5)],
-                           sync, min_s=0.05, max_reps=64)
+    per_iter = dt / (5 * reps)
     rows_eval = s1["legal_rows"] - s0["legal_rows"]
-    out["tables_65536_dqn_inference"] = {
-        "env_steps_per_s": T * 5 * reps / dt, "us_per_iteration": dt / (5 * reps) * 1e6, "iterations": 5 * reps,
-        "us_net": dtn / (5 * repn) * 1e6, "us_net_tables_gemms": dtt / (5 * rept) * 1e6,
-        "us_net_rows_q_slab": (dtn / (5 * repn) - dtt / (5 * rept)) * 1e6, "us_env": dte / (5 * repe) * 1e6,
-        "q_evals_per_s": rows_eval / dt, "mean_legal_moves": rows_eval / max(1, s1["plies"] - s0["plies"]),
-        "dtype_net": "f32", "net": "NetCooperationSimplify-shaped QNet(6 + 1 planes), torch.manual_seed(0), eval()",
-        "loop": "FactorisedQ.tables_packed(face, actors' hands) [ddz_q_features_packed + one torch GEMM per rank over the "
-                "(rank, count, table) rows a legal move can use] -> ddz_q_slab_packed -> ddz_policy_step_slab(greedy, face "
-                "= EnvCooperationSimplify): every legal action of every table gets its Q value each iteration; one "
-                "128-byte device -> host copy per iteration (the GEMM shapes)"}
-    hc = env.actor_hands().clamp(max=4)
-    hc[:, 13:].clamp_(max=1)
-    rows_needed = 15 * T + int(hc.sum())
-    out["tables_65536_dqn_inference"]["packed_rows_per_table"] = rows_needed / T
-    loop.fq.batched_gemm = True    # one batched fc1 GEMM over segments padded to the longest instead of fifteen exact ones
-    out["tables_65536_dqn_inference"]["batched_gemm_padding_share"] = 1.0 - rows_needed / loop.fq.pack(env.actor_hands())[1][15]
-    loop.run(2)
-    dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.2, max_reps=64)
-    out["tables_65536_dqn_inference"]["batched_gemm_env_steps_per_s"] = T * 5 * reps / dt
-    del loop
-    # the same with fixed shapes (all 69 (rank, count) rows of every table, nothing on the host)
-    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, packed=False)
-    loop.run(2)
-    dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.3, max_reps=64)
-    out["tables_65536_dqn_inference"]["fixed_shapes_env_steps_per_s"] = T * 5 * reps / dt
+    res = {"env_steps_per_s": T / per_iter, "us_per_iteration": per_iter * 1e6, "iterations": 5 * reps,
+           "q_evals_per_s": rows_eval / dt, "mean_legal_moves": rows_eval / max(1, s1["plies"] - s0["plies"]),
+           "dtype_net": "f32", "net": "NetCooperationSimplify-shaped QNet(6 + 1 planes), torch.manual_seed(0), eval()",
+           "loop": loop.describe()}
+    # per stage: HIP events around every stage of 10 iterations on the launching stream
+    stages = loop.profile(10)
+    res["stages_us"] = {k: v["us"] for k, v in stages.items()}
+    blocks = {}
+    flop_total = 0.0
+    for name, st in stages.items():
+        if st.get("flop"):
+            blocks[name] = mfma_block(st["kernel"], st["flop"], st["us"] * 1e-6, note=st.get("note", ""))
+            flop_total += st["flop"]
+        elif st.get("bytes"):
+            blocks[name] = hbm_block(st["kernel"], st["bytes"], st["us"] * 1e-6, note=st.get("note", ""))
+    res["roofline"] = mfma_block("the whole iteration (all launches)", flop_total, per_iter,
+                                 note="network FLOP of one iteration (first layer + fc1, fp32) / the iteration's wall time; "
+                                      "stages: per-kernel blocks", stages=blocks)
+    if hasattr(loop, "variants"):
+        res["variants"] = loop.variants(timed_loop, sync)
     del loop, net
-    # the stepping launch alone (uniformly random legal moves drawn in the kernel: every selection is in its list), and
-    # the same with the new lists packed to CSR every iteration (what a ragged NN forward over all legal moves consumes)
-    dt, reps = timed_loop(lambda: [env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True) for _ in range(20)], sync)
-    out["tables_65536_step_slab_only"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6,
-                                          "loop": "step_slab(RANDOM)"}
+    return res
 
-    def csr_iter():
-        env.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
-        env.slab_to_csr(rows_per_table=128)
 
-    dt, reps = timed_loop(lambda: [csr_iter() for _ in range(20)], sync)
-    out["tables_65536_step_slab_csr_lists"] = {"env_steps_per_s": T * 20 * reps / dt, "us_per_iteration": dt / (20 * reps) * 1e6,
-                                               "loop": "step_slab(RANDOM) + slab_to_csr: offsets / rows / ids as ddz_legal writes them"}
-    env.csr_rows = env.csr_ids = None
-    env._csr_cap = 0
-    # (3) configs[3]: farmers played by the rule-based opponent (Env.step_auto), the lord by the random policy
-    def auto_iter():
-        ids = env.auto_choose(0b101)
-        env.step_slab(ids, pkg.STEP_IDS, auto_reset=True)
+_PROFILE_CACHE = {}
 
-    env.reset()           # whole episodes against the rule agent: start from fresh deals and play past the first
-    env.legal_slab()      # games (a rule-agent game lasts ~25 plies) before episodes are counted
-    for _ in range(40):
-        auto_iter()
-    s0 = env.stats()
-    dt, reps = timed_loop(lambda: [auto_iter() for _ in range(5)], sync, min_s=0.2, max_reps=40)
-    s1 = env.stats()
-    eps = max(1, s1["episodes"] - s0["episodes"])
-    lord, farm = s1["lord_wins"] - s0["lord_wins"], (s1["up_wins"] - s0["up_wins"]) + (s1["down_wins"] - s0["down_wins"])
-    out["tables_65536_rule_opponent"] = {
-        "env_steps_per_s": T * 5 * reps / dt, "us_per_iteration": dt / (5 * reps) * 1e6,
-        "mean_episode_return": {"lord": 100.0 * (lord - farm) / eps, "up": 50.0 * (farm - lord) / eps,
-                                "down": 50.0 * (farm - lord) / eps},
-        "episodes": eps, "loop": "auto_choose(farmers) + step_slab(IDS), lord = engine RNG; reward_dict of game.py:13-14"}
-    assert env.status() == 0
-    del env, q, face
+
+def _profile(name):
+    if name not in _PROFILE_CACHE:
+        try:
+            _PROFILE_CACHE[name] = json.load(open(os.path.join(REPO, "profiles", name)))
+        except Exception:
+            _PROFILE_CACHE[name] = None
+    return _PROFILE_CACHE[name]
+
+
+def hbm_block(kernel, bytes_per_launch, seconds_per_launch, **extra):
+    """roofline object against the HBM roof: ALGORITHMIC bytes of one launch (SURVEY 8d per-unit figure x units) / the
+    launch's measured duration."""
+    ach = bytes_per_launch / seconds_per_launch / 1e9
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+           "kernel": kernel, "launch_us": seconds_per_launch * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch}
+    out.update(extra)
     return out
 
 
-def issue_roofline(steps_timed, dur_launch):
-    """The bound this integer path really runs into: vector-ALU issue.  Instructions per env step and the clock come
-    from the committed PMC passes (profiles/pmc_traffic.json), the cost of an instruction from the measured table of
-    tools/valu_issue_probe.hip (profiles/r02_valu_issue_probe.json), the rate is live."""
-    try:
-        prof = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("k_rollout", {})
-        v = prof["valu"]
-        probe = json.load(open(os.path.join(REPO, "profiles", "r02_valu_issue_probe.json")))
-    except Exception:
+def mfma_block(kernel, flop_per_launch, seconds_per_launch, **extra):
+    """roofline object against the dense fp32 matrix roof (v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s, exact f32)."""
+    ach = flop_per_launch / seconds_per_launch / 1e12
+    out = {"bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_TFLOPS,
+           "kernel": kernel, "launch_us": seconds_per_launch * 1e6, "flop_per_launch": flop_per_launch, "dtype": "f32"}
+    out.update(extra)
+    return out
+
+
+def issue_block(key, units_per_launch, seconds_per_launch):
+    """The bound this integer path really runs into: vector-ALU issue.  LIVE: the launch duration (and so the rate).
+    REPLAYED from committed profiles, each named in `sources`: the kernel's VALU instructions per unit and its clock
+    (profiles/pmc_kernels.json: rocprofv3 --pmc passes), its static opcode mix (profiles/r04_opcode_mix.json:
+    tools/opcode_mix.py over the code object) and the cost of an instruction of each class (profiles/
+    r02_valu_issue_probe.json: tools/valu_issue_probe.hip)."""
+    pk, mixes, probe = _profile("pmc_kernels.json"), _profile("r04_opcode_mix.json"), _profile("r02_valu_issue_probe.json")
+    if not pk or key not in pk or not mixes or not probe:
         return None
-    cyc = {}
-    for r in probe["rows"]:
-        if r["waves_per_simd"] == 4:  # k_rollout runs four waves per SIMD at 4096 tables
-            cyc[r["kind"]] = r["cycles_per_instr_per_simd"]
+    k = pk[key]
+    mix = mixes["kernels"].get(k["mix_key"])
+    if mix is None:
+        return None
+    wps = 4 if k.get("waves_per_simd", 4) >= 4 else 2
+    cyc = {r["kind"]: r["cycles_per_instr_per_simd"] for r in probe["rows"] if r["waves_per_simd"] == wps}
     full = (cyc["v_add_u32"] + cyc["v_and_b32/v_or_b32"]) / 2            # plain 32-bit VALU
     half = (cyc["v_lshlrev_b64"] + cyc["v_add_co_u32+v_addc_co_u32"] + cyc["v_sub_co_u32+v_subb_co_u32"]
             + cyc["v_mul_lo_u32"] + cyc["v_mbcnt_lo+v_mbcnt_hi"]) / 5   # 64-bit shifts, carry chains, mul, mbcnt, compares
     lane = cyc["v_readlane_b32"]                                          # v_readlane / v_readfirstlane
-    mix = prof.get("valu_mix") or {"share_half_rate": 0.5, "share_readlane": 0.0, "source": "assumed"}
-    sh, sr = mix["share_half_rate"], mix.get("share_readlane", 0.0)
+    sh, sr = mix["share_half_rate"], mix["share_readlane"]
     cpi = (1 - sh - sr) * full + sh * half + sr * lane
     simds = 256 * 4
-    peak = simds * v["clock_GHz"] * 1e9 / cpi
-    ach = v["SQ_INSTS_VALU_per_env_step"] * steps_timed / dur_launch
+    peak = simds * k["clock_GHz"] * 1e9 / cpi
+    ach = k["valu_per_unit"] * units_per_launch / seconds_per_launch
     return {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
-            "valu_insts_per_env_step": v["SQ_INSTS_VALU_per_env_step"], "cycles_per_instr_full_rate": full,
-            "cycles_per_instr_half_rate": half, "cycles_per_instr_readlane": lane, "share_half_rate": sh,
-            "share_readlane": sr, "mix_weighted_cycles_per_instr": cpi, "share_source": mix.get("source", "")[:160],
-            "peak_if_all_full_rate": simds * v["clock_GHz"] / full, "peak_if_all_half_rate": simds * v["clock_GHz"] / half,
-            "note": "cycles per wave64 instruction per SIMD measured by tools/valu_issue_probe.hip at 4 waves/SIMD "
-                    "(profiles/r02_valu_issue_probe.json): ~2.4 for plain 32-bit ops (the guide's 2-cycle SIMD-32 figure), "
-                    "~4.5 for 64-bit shifts / carry chains / v_mul_lo / v_mbcnt / compares, ~6.3 for v_readlane; the peak "
-                    "weights them by the kernel's opcode mix"}
+            "kernel": k["mix_key"], "launch_us": seconds_per_launch * 1e6, "unit_of_work": k["unit"],
+            "valu_insts_per_unit": k["valu_per_unit"], "salu_insts_per_unit": k.get("salu_per_unit"),
+            "branch_insts_per_unit": k.get("branch_per_unit"), "wait_any_share_of_wave_cycles": k.get("wait_any_share"),
+            "clock_GHz": k["clock_GHz"], "cycles_per_instr_full_rate": full, "cycles_per_instr_half_rate": half,
+            "cycles_per_instr_readlane": lane, "share_half_rate": sh, "share_readlane": sr,
+            "mix_weighted_cycles_per_instr": cpi, "peak_if_all_full_rate": simds * k["clock_GHz"] / full,
+            "peak_if_all_half_rate": simds * k["clock_GHz"] / half,
+            "live": ["launch_us", "achieved", "frac"],
+            "sources": {"valu_insts_per_unit, salu / branch / wait shares, clock_GHz": k["source"] + " via profiles/pmc_kernels.json",
+                        "share_half_rate, share_readlane": "profiles/r04_opcode_mix.json (static opcode histogram of the code object)",
+                        "cycles_per_instr_*": f"profiles/r02_valu_issue_probe.json ({wps} waves per SIMD)"},
+            "note": "replayed inputs (see sources) x the live launch duration; cycles per wave64 instruction per SIMD: ~2.4 "
+                    "plain 32-bit, ~4.5 for 64-bit shifts / carry chains / v_mul_lo / v_mbcnt / compares, ~6.3 v_readlane"}
 
 
 def spawn_ranks(n):
@@ -370,7 +504,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tables", type=int, default=0,
-                    help="tables per GPU; default 4096 at N = 1 (configs[1]), 65536 at N > 1 (configs[4])")
+                    help="tables per GPU; default 65536 at every N (the largest single-GPU configuration; configs[4] at N = 8)")
+    ap.add_argument("--allow-leg-failure", action="store_true",
+                    help="N = 1: report a failing leg in the JSON (`errors`) and exit 0 (default: exit 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the short legs of the other configs")
@@ -409,7 +545,7 @@ def main():
             import datetime
             dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
 
-    T = a.tables if a.tables > 0 else (4096 if world == 1 else 65536)
+    T = a.tables if a.tables > 0 else T_FULL
     total_tables = T * world
     _, base = ddist.shard_tables(total_tables, rank, world)
     env = pkg.BatchedEnv(T, seed=0, device=dev, table_id_base=base, want_ids=False)
@@ -442,9 +578,14 @@ def main():
         env.rollout_random(KL)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = [T * K * R / dt]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        mine = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # every rank's own clock over the same K x R iterations
+        per_rank = [T * K * R / float(x.item()) for x in every]
         dt = float(tmax.item())
     s1 = env.stats()
     st = {k: s1[k] - s0[k] for k in s1}
@@ -481,6 +622,17 @@ def main():
             tmx = torch.tensor([dtx], dtype=torch.float64, device=dev)
             dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
             dtx = float(tmx.item())
+            # the gather on its own (nothing overlapping it): the second half-batch's packed records once more
+            pk_b = stage(pack(traj_b))
+            barrier()
+            tg = time.perf_counter()
+            gg = ddist.gather_trajectories(pk_b, dst=0, shard_sizes=shard)
+            barrier()
+            dtg = time.perf_counter() - tg
+            tmg = torch.tensor([dtg], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmg, op=dist.ReduceOp.MAX)
+            dtg = float(tmg.item())
+            del gg, pk_b
             digest = None
             if rank == 0:
                 assert ga.shape == (half, total_tables, pkg.TRAJ_PACKED_BYTES) and gb.shape == (KX - half, total_tables, pkg.TRAJ_PACKED_BYTES)
@@ -493,6 +645,10 @@ def main():
                 digest = int((x * 31 + (x >> 13) + torch.arange(x.numel(), device=dev) * x).sum().item())
             exchange = {"steps": KX, "iterations_before": W + KL * (RL + 1), "env_steps_per_s_with_gather": total_tables * KX / dtx,
                         "bytes_to_rank0": (world - 1) * KX * T * pkg.TRAJ_PACKED_BYTES, "seconds": dtx, "digest": digest,
+                        "gather_only": {"seconds": dtg, "bytes_into_rank0": (world - 1) * (KX - half) * T * pkg.TRAJ_PACKED_BYTES,
+                                        "GBps_into_rank0": (world - 1) * (KX - half) * T * pkg.TRAJ_PACKED_BYTES / dtg / 1e9,
+                                        "collective": "gather (dst = rank 0) of uint8 [iterations, tables, 8], "
+                                                      + ("gloo, host-staged (rehearsal)" if a.rehearse else "RCCL over xGMI")},
                         "note": "trajectory records (32 B per ply per table) written, packed to 8 B and gathered to rank 0, pipelined "
                                 "in two half-batches; measured after the headline region"}
             del traj_a, traj_b, ga, gb
@@ -500,6 +656,7 @@ def main():
             exchange = {"error": repr(ex)[:300]}
             print(f"[bench] rank {rank}: trajectory-gather leg FAILED: {ex!r}", file=sys.stderr, flush=True)
     mean_a = st["legal_rows"] / max(1, st["plies"])
+    leg_errors = []
 
     # ---- duration of the dominant kernel: all K iterations run inside ONE k_rollout launch; two HIP events around
     # every launch on the launching stream, repeated until >= 50 ms of kernel time are summed
@@ -518,21 +675,21 @@ def main():
     steps_per_launch = steps_timed / n_launch
     b_launch = b_step * steps_per_launch
     dominant = "k_rollout"
+    traffic, traffic_source = None, None
+    prof = (_profile("pmc_traffic.json") or {}).get(dominant, {})
+    if prof.get("hbm_bytes_per_env_step") is not None:
+        traffic = prof["hbm_bytes_per_env_step"] * steps_per_launch
+        traffic_source = ("REPLAYED, not measured in this run: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                          "separate passes, FETCH doubled per the gfx950 note; " + str(prof.get("workload", "")) + ") x this run's env steps per launch")
+    issue = issue_block("k_rollout", steps_per_launch, dur_launch)
     ach = b_launch / dur_launch / 1e9
-    traffic = None
-    try:
-        prof = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dominant, {})
-        per_step = prof.get("hbm_bytes_per_env_step")
-        traffic = per_step * steps_per_launch if per_step is not None else None
-    except Exception:
-        traffic = None
-    issue = issue_roofline(steps_per_launch, dur_launch)
 
     # ---- the same loop with packed CSR lists (one launch per iteration): a number, not the headline
     env.rollout_random_csr(20)
     torch.cuda.synchronize(dev)
     dtc, repc = timed_loop(lambda: env.rollout_random_csr(50), lambda: torch.cuda.synchronize(dev))
     csr_rate = T * 50 * repc / dtc
+    csr_us = dtc / (50 * repc) * 1e6
 
     if rank == 0:
         out = {
@@ -542,15 +699,20 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "timed_steps": K * R, "repeats_of_the_steps_launch": R, "iterations_per_launch": KL, "launches_timed": RL,
             "timed_seconds": dt,
-            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list only (no NN), "
-                                   f"auto-reset; BASELINE.json {'configs[1]' if world == 1 else 'configs[4] (65,536 tables per GPU)'}",
+            "config": {"workload": f"{T} tables per GPU, random policy (engine RNG), legal-move list only (no NN), auto-reset: "
+                                   "the workload of BASELINE.json configs[1] at the largest single-GPU table count "
+                                   "(65,536 per GPU: configs[2] / configs[3]; configs[4] = 8 x 65,536), the same per-GPU "
+                                   "workload at every N",
                        "tables_per_gpu": T, "total_tables": total_tables,
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
                        "list_layout": "slab (fixed-stride segment per table)",
-                       "csr_env_steps_per_s": csr_rate,
+                       "csr_env_steps_per_s": csr_rate, "csr_us_per_iteration": csr_us,
+                       "csr_note": "the same loop with packed CSR lists (offsets / rows as ddz_legal writes them: SURVEY 8(d) "
+                                   "config 2 'outputs = CSR legal list only') beside the slab layout of `value`",
+                       "per_rank_env_steps_per_s": per_rank,
                        "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": dominant,
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dominant,
                          "launch_us": dur_launch * 1e6, "launches_timed": n_launch, "env_steps_per_launch": steps_per_launch,
                          "us_per_iteration": dur_launch * 1e6 / KL, "iterations_per_launch": KL,
                          "algorithmic_bytes_per_env_step": b_step,
@@ -564,24 +726,30 @@ def main():
         if exchange and "env_steps_per_s_with_gather" in exchange:
             out["env_steps_per_s_with_gather"] = exchange["env_steps_per_s_with_gather"]
         if world == 1 and not a.no_configs:
+            del env                                    # (the legs make their own environments)
             try:
-                out["configs"] = other_config_legs(pkg, torch, dev)
-            except Exception as ex:
+                out["configs"] = other_config_legs(pkg, torch, dev, leg_errors)
+            except Exception as ex:  # noqa: BLE001
                 out["configs"] = {"error": repr(ex)[:300]}
+                leg_errors.append({"leg": "configs", "error": repr(ex)[:300]})
                 print(f"[bench] config legs FAILED: {ex!r}", file=sys.stderr, flush=True)
             try:
                 out["configs"]["stress_plane_rich_leads"] = stress_leg(pkg, torch, dev)
-            except Exception as ex:
+            except Exception as ex:  # noqa: BLE001
                 out["configs"]["stress_plane_rich_leads"] = {"error": repr(ex)[:300]}
+                leg_errors.append({"leg": "stress_plane_rich_leads", "error": repr(ex)[:300]})
                 print(f"[bench] stress leg FAILED: {ex!r}", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(T, a.cpu_budget)   # the same workload, a bounded sample
+        out["errors"] = leg_errors                      # legs that raised: a non-empty list is a non-zero exit
         print(json.dumps(out), flush=True)
     failed = bool(exchange and "error" in exchange)
     if world > 1:
         dist.destroy_process_group()
     if failed and not a.allow_exchange_failure:
         sys.exit(3)   # loud: a broken gather must not look like a green run
+    if leg_errors and not a.allow_leg_failure:
+        sys.exit(4)   # ... and neither must a broken leg (the configs[2] / configs[3] / stress figures come from them)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libddz_hip.so")
 LIB_JK = os.path.join(CSRC, "libddz_hip_jk.so")
 SOURCES = ["ddz_engine.hip"]
-DEPS = ["ddz_device.h", "ddz_build_table.h", "ddz_auto.h", "ddz_auto2.h", os.path.join("..", "..", "include", "ddz_env.h")]
+DEPS = ["ddz_device.h", "ddz_build_table.h", "ddz_auto.h", "ddz_auto2.h", "ddz_qnet.h", os.path.join("..", "..", "include", "ddz_env.h")]
 
 
 def hipcc():

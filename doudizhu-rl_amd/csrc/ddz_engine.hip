@@ -2123,6 +2123,8 @@ __global__ __launch_bounds__(QH) void k_q_feat(const float4* __restrict__ face, 
   }
 }
 
+#include "ddz_qnet.h"
+
 __global__ __launch_bounds__(BLOCK) void k_classify(const uint4* __restrict__ rows, int64_t n,
                                                     uint32_t* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -3166,6 +3168,93 @@ int ddz_q_slab_packed(ddz_env_t* e, const float* u, const int32_t* row_index, co
   hipLaunchKernelGGL(k_q_slab<true>, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
                      (const float4*)u, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts, (const uint4*)rows, stride, q,
                      row_index, row0, (const float4*)table_term, e->sc.status);
+  return check_launch();
+}
+
+// ---- the "needed rows" form of the ragged Q forward (ddz_qnet.h) ----
+int64_t ddz_q_need_scratch_bytes(int64_t n_tables) {
+  if (n_tables <= 0) return 0;
+  const int64_t nblk = (n_tables + QN_TPB - 1) / QN_TPB;
+  return align_up(8 * n_tables, 256) + align_up(nblk * 16 * 4, 256);
+}
+
+int ddz_q_need(ddz_env_t* e, const int32_t* counts, const int8_t* rows, int64_t stride, int64_t row_capacity, void* scratch,
+               int64_t scratch_bytes, int32_t* row_index, int32_t* seg, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!counts || !rows || !scratch || !row_index || !seg || stride < 1) return DDZ_EINVAL;
+  if (!al(counts, 4) || !al(rows, 16) || !al(scratch, 256) || !al(row_index, 16) || !al(seg, 4)) return DDZ_EINVAL;
+  if (row_capacity < 15 * FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
+  if (scratch_bytes < ddz_q_need_scratch_bytes(e->T)) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = (e->T + QN_TPB - 1) / QN_TPB;
+  uint64_t* need = (uint64_t*)scratch;
+  int32_t* blk = (int32_t*)((uint8_t*)scratch + align_up(8 * e->T, 256));
+  hipLaunchKernelGGL(k_q_need_mask, dim3((unsigned)nblk), dim3(QN_TPB), 0, st, counts, (const uint4*)rows, stride, e->T, need, blk);
+  hipLaunchKernelGGL(k_q_need_scan, dim3(1), dim3(256), 0, st, blk, nblk, seg, row_capacity);
+  hipLaunchKernelGGL(k_q_need_assign, dim3((unsigned)nblk), dim3(QN_TPB), 0, st, (const uint64_t*)need, e->T, (const int32_t*)blk,
+                     (const int32_t*)seg, row_index, e->sc.status);
+  return check_launch();
+}
+
+int ddz_q_features_needed(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                          const float* acnt, const int32_t* row_index, float* y0, float* dy, int64_t row_capacity, void* stream) {
+  if (!face || !wf || !bias || !acnt || !row_index || !y0 || !dy || n_tables <= 0) return DDZ_EINVAL;
+  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(row_index, 16) || !al(y0, 4) || !al(dy, 4)) return DDZ_EINVAL;
+  if (row_capacity < 1 || row_capacity > (((int64_t)1 << 31) - 1) / QH || n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  const dim3 grid((unsigned)((n_tables + QF_TILE - 1) / QF_TILE)), block(QH);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* f = (const float4*)face;
+  switch (planes) {
+    case 4: hipLaunchKernelGGL(k_q_feat_needed<4>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y0, dy, row_capacity, row_index); break;
+    case 6: hipLaunchKernelGGL(k_q_feat_needed<6>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y0, dy, row_capacity, row_index); break;
+    case 7: hipLaunchKernelGGL(k_q_feat_needed<7>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y0, dy, row_capacity, row_index); break;
+    case 9: hipLaunchKernelGGL(k_q_feat_needed<9>, grid, block, 0, st, f, n_tables, wf, bias, acnt, y0, dy, row_capacity, row_index); break;
+    default: return DDZ_EINVAL;
+  }
+  return check_launch();
+}
+
+int ddz_q_fc1_dense(int device, const float* a, int64_t n_rows, int64_t k, const float* w, float* c, void* stream) {
+  if (!a || !w || !c || n_rows <= 0 || k < FC_K || k % FC_K || k > (1 << 20)) return DDZ_EINVAL;
+  if (!al(a, 16) || !al(w, 16) || !al(c, 4)) return DDZ_EINVAL;
+  if (n_rows > ((int64_t)1 << 31) - FC_M) return DDZ_ECAP;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_fc1<false>, dim3((unsigned)((n_rows + FC_M - 1) / FC_M)), dim3(256), 0, (hipStream_t)stream, a, k, w, c,
+                     n_rows, (int)k, (const int32_t*)nullptr);
+  return check_launch();
+}
+
+int ddz_q_fc1_rows(int device, const float* dy, const int32_t* seg, const float* w2, float* d, int64_t row_capacity, void* stream) {
+  if (!dy || !seg || !w2 || !d) return DDZ_EINVAL;
+  if (!al(dy, 16) || !al(w2, 16) || !al(d, 4) || !al(seg, 4)) return DDZ_EINVAL;
+  if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(256), 0, (hipStream_t)stream, dy, (int64_t)QH, w2, d,
+                     (int64_t)0, QH, seg);
+  return check_launch();
+}
+
+int ddz_q_slab_needed(ddz_env_t* e, const float* h0, const float* d, int64_t row_capacity, const int32_t* row_index, const float* z,
+                      int64_t hidden, const float* w2, const float* b2, const int32_t* counts, const int8_t* rows, int64_t stride,
+                      float* q, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(h0, 16) || !al(d, 16) || !al(z, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4) || !al(row_index, 4))
+    return DDZ_EINVAL;
+  if (!h0 || !d || !z || !w2 || !b2 || !counts || !rows || !q || !row_index || hidden != QH || stride < 1 || row_capacity < 1) return DDZ_EINVAL;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  int64_t v = (e->T + 4095) / 4096;
+  const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
+  const int64_t per_block = (int64_t)WPB * tpw;
+  hipLaunchKernelGGL(k_q_slab_needed, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
+                     (const float4*)h0, (const float4*)d, row_capacity, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts,
+                     (const uint4*)rows, stride, q, row_index, e->sc.status);
   return check_launch();
 }
 

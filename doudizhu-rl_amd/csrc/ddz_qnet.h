@@ -1,0 +1,409 @@
+// ddz_qnet.h -- the "needed rows" form of the ragged Q forward (BASELINE configs[2]: NetCooperationSimplify inference in the
+// loop; net.py:81-102, dqn.py:50-71, game.py:95-104), device side.  Included by ddz_engine.hip inside its anonymous
+// namespace, after k_q_slab / k_q_feat (it uses QH, QP_COLS, qp_col, pack_row, ge_mask, rl64, rfl, wave_sum_f32).
+//
+// With the first layer factorised per (table, rank, count) (ddz_engine.hip k_q_feat, dqn_glue.FactorisedQ):
+//     fc1 pre-activation of action j of table t = tab[t] + sum_r W2[r]^T Y[t][r][cnt_jr]          (+ Z[r][cnt_jr], weights only)
+//                                               = H0[t]  + sum_{r touched by j} ( D[t][r][cnt_jr] + Z[r][cnt_jr] )
+//     H0[t]      = tab[t] + sum_r W2[r]^T Y[t][r][0]            ONE dense GEMM [T, 15 * 256] x [15 * 256, 256], K = 3840
+//     D[t][r][c] = W2[r]^T (Y[t][r][c] - Y[t][r][0]),  c >= 1   only for the (r, c) some LEGAL MOVE of table t uses
+// The rows of D are the "needed rows": a follow needs one or two (the ranks / counts of the moves that beat `last`), a lead
+// about as many as the actor holds cards; 15 count-0 rows per table collapse into H0.  Against the packed form of round 3
+// (15 + cards-in-hand rows per table through fifteen GEMMs, segment sizes crossing to the host every iteration) this is
+// ~40 % fewer fc1 FLOP, no per-row count-0 reads in the row stage, and NOTHING on the host: the needed rows are found on the
+// device from the slab lists (k_q_need_*), laid out in rank segments whose starts live in device memory, and multiplied by a
+// hand-written fp32 MFMA kernel (k_fc1: v_mfma_f32_32x32x2_f32, exact f32 = a k-ordered fmaf chain) that reads the segment
+// table itself.  The same kernel does the dense GEMM.
+#pragma once
+
+// ---- 1. which rows are needed: three small launches, deterministic layout ---------------------------------------------
+// need[t] = 64-bit set over the columns of row_index (QP_COLS: (r < 13, c = 1..4) at 4 r + c - 1, the jokers' count 1 at
+// 52 / 53): column set <=> some legal move of table t takes exactly c cards of rank r.
+constexpr int QN_TPB = 256;          // tables per block of the need kernels (one thread per table)
+constexpr int QN_SEG_WORDS = 40;     // seg[0..15] first row of rank r's segment (multiples of FC_M), [15] = rows in use,
+                                     // seg[16..31] first TILE of rank r, [31] = tiles in use, seg[32] = rows needed, [33] = overflow
+constexpr int FC_M = 128, FC_K = 16, FC_N = 256;   // k_fc1's tile: 128 rows x all 256 fc1 outputs, K in chunks of 16
+
+__device__ __forceinline__ uint64_t q_need_of_row(uint64_t nib) {
+  // nibble c in 1..4 of rank r < 13 -> bit c - 1 of the same nibble (SWAR over the 13 nibbles); jokers -> bits 52, 53
+  const uint64_t M = 0x0001111111111111ull;  // bit 0 of nibbles 0..12
+  const uint64_t b0 = nib & M, b1 = (nib >> 1) & M, b2 = (nib >> 2) & M;
+  const uint64_t e1 = b0 & ~b1 & ~b2, e2 = b1 & ~b0 & ~b2, e3 = b0 & b1 & ~b2, e4 = b2;
+  uint64_t out = e1 | (e2 << 1) | (e3 << 2) | (e4 << 3);
+  out |= (uint64_t)(((nib >> 52) & 15u) != 0) << 52;
+  out |= (uint64_t)(((nib >> 56) & 15u) != 0) << 53;
+  return out;
+}
+// per-rank row counts of a need set, packed: 15 fields of 12 bits in three words (5 ranks each; a block of 256 tables sums to
+// at most 1024 per rank)
+__device__ __forceinline__ void q_need_counts(uint64_t need, uint64_t w[3]) {
+  w[0] = w[1] = w[2] = 0;
+#pragma unroll
+  for (int r = 0; r < 15; ++r) {
+    const uint32_t c = r < 13 ? (uint32_t)__popc((uint32_t)(need >> (4 * r)) & 15u) : (uint32_t)((need >> (52 + r - 13)) & 1u);
+    w[r / 5] |= (uint64_t)c << (12 * (r % 5));
+  }
+}
+__device__ __forceinline__ uint32_t q_need_field(const uint64_t w[3], int r) { return (uint32_t)(w[r / 5] >> (12 * (r % 5))) & 0xFFFu; }
+
+// (a) one thread per table: OR over the table's slab list -> need[t]; per block the per-rank row counts -> blk[b][16]
+__global__ __launch_bounds__(QN_TPB) void k_q_need_mask(const int32_t* __restrict__ counts, const uint4* __restrict__ rows,
+                                                        int64_t stride, int64_t T, uint64_t* __restrict__ need,
+                                                        int32_t* __restrict__ blk) {
+  const int64_t t = (int64_t)blockIdx.x * QN_TPB + threadIdx.x;
+  uint64_t m = 0;
+  if (t < T) {
+    int n = counts[t];
+    if (n < 0 || n > stride) n = 0;
+    const uint4* lr = rows + t * stride;
+    for (int j = 0; j < n; ++j) m |= q_need_of_row(pack_row(lr[j]));
+    need[t] = m;
+  }
+  uint64_t w[3];
+  q_need_counts(m, w);
+  __shared__ uint64_t s[3][QN_TPB / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // wave sum of the packed fields (no field overflows: <= 64 * 4 per wave)
+    uint64_t v = w[k];
+    for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)__shfl_xor((uint32_t)(v >> 32), d) << 32) | (uint64_t)__shfl_xor((uint32_t)v, d);
+    if (lane == 0) s[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    uint64_t tot[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+      for (int q = 0; q < QN_TPB / 64; ++q) tot[k] += s[k][q];
+    blk[(int64_t)blockIdx.x * 16 + threadIdx.x] = threadIdx.x < 15 ? (int32_t)q_need_field(tot, (int)threadIdx.x) : 0;
+  }
+}
+
+// (b) one block: exclusive scan of blk[][r] over the blocks (in place) and the segment table.  Rank r's segment starts at a
+// multiple of FC_M (a k_fc1 tile never straddles two ranks); rows behind a segment's last needed row are padding.
+__global__ __launch_bounds__(256) void k_q_need_scan(int32_t* __restrict__ blk, int64_t nblk, int32_t* __restrict__ seg,
+                                                     int64_t row_capacity) {
+  __shared__ int32_t s_part[256][16];
+  __shared__ int32_t s_tot[16];
+  const int tid = threadIdx.x;
+  const int64_t per = (nblk + 255) / 256;   // blocks per thread, consecutive
+  int32_t acc[15];
+#pragma unroll
+  for (int r = 0; r < 15; ++r) acc[r] = 0;
+  for (int64_t b = tid * per; b < (tid + 1) * per && b < nblk; ++b)
+#pragma unroll
+    for (int r = 0; r < 15; ++r) acc[r] += blk[b * 16 + r];
+#pragma unroll
+  for (int r = 0; r < 15; ++r) s_part[tid][r] = acc[r];
+  __syncthreads();
+  if (tid < 15) {  // exclusive scan over the 256 partials of rank tid
+    int32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const int32_t v = s_part[i][tid]; s_part[i][tid] = run; run += v; }
+    s_tot[tid] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 15; ++r) acc[r] = s_part[tid][r];
+  for (int64_t b = tid * per; b < (tid + 1) * per && b < nblk; ++b)
+#pragma unroll
+    for (int r = 0; r < 15; ++r) { const int32_t v = blk[b * 16 + r]; blk[b * 16 + r] = acc[r]; acc[r] += v; }
+  if (tid == 0) {
+    int64_t row = 0, needed = 0;
+    int32_t over = 0;
+    for (int r = 0; r < 15; ++r) {
+      seg[r] = (int32_t)row;
+      seg[16 + r] = (int32_t)(row / FC_M);
+      needed += s_tot[r];
+      int64_t len = ((int64_t)s_tot[r] + FC_M - 1) / FC_M * FC_M;
+      if (row + len > row_capacity) { len = (row_capacity - row) / FC_M * FC_M; over = 1; }  // (k_q_need_assign drops what does not fit)
+      row += len;
+    }
+    seg[15] = (int32_t)row;
+    seg[31] = (int32_t)(row / FC_M);
+    seg[32] = (int32_t)needed;
+    seg[33] = over;
+  }
+}
+
+// (c) one thread per table: row of every needed (r, c) = seg[r] + rows of rank r in the blocks before + in the tables before
+// inside the block + position inside the table (ascending c); row_index[t][64], -1 = not needed.
+__global__ __launch_bounds__(QN_TPB) void k_q_need_assign(const uint64_t* __restrict__ need, int64_t T, const int32_t* __restrict__ blk,
+                                                          const int32_t* __restrict__ seg, int32_t* __restrict__ row_index,
+                                                          int32_t* __restrict__ status) {
+  const int64_t t = (int64_t)blockIdx.x * QN_TPB + threadIdx.x;
+  const uint64_t m = t < T ? need[t] : 0;
+  uint64_t w[3], inc[3];
+  q_need_counts(m, w);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ uint64_t s[3][QN_TPB / 64];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // inclusive wave scan of the packed fields
+    uint64_t v = w[k];
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = ((uint64_t)__shfl_up((uint32_t)(v >> 32), d) << 32) | (uint64_t)__shfl_up((uint32_t)v, d);
+      if (lane >= d) v += o;
+    }
+    inc[k] = v;
+    if (lane == 63) s[k][wv] = v;
+  }
+  __syncthreads();
+  uint64_t ex[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint64_t before = 0;
+    for (int q = 0; q < wv; ++q) before += s[k][q];
+    ex[k] = before + inc[k] - w[k];
+  }
+  if (t >= T) return;
+  int32_t out[QP_COLS];
+#pragma unroll
+  for (int i = 0; i < QP_COLS; ++i) out[i] = -1;
+  bool dropped = false;
+#pragma unroll
+  for (int r = 0; r < 15; ++r) {
+    const int32_t lo = seg[r], hi = seg[r + 1];   // (seg[15] = the end of rank 14's segment)
+    int32_t row = lo + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
+    if (r < 13) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((m >> (4 * r + c)) & 1u) { if (row < hi) out[4 * r + c] = row; else dropped = true; ++row; }
+    } else if ((m >> (52 + r - 13)) & 1u) {
+      if (row < hi) out[52 + r - 13] = row; else dropped = true;
+    }
+  }
+  int4* dst = (int4*)(row_index + t * QP_COLS);
+#pragma unroll
+  for (int i = 0; i < QP_COLS / 4; ++i) dst[i] = make_int4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+  if (dropped) atomicOr(status, 2);   // row capacity overflow (cannot happen with capacity >= 20 T + 15 * 128)
+}
+
+// ---- 2. first layer for the needed rows ----------------------------------------------------------------------------------
+// As k_q_feat (ddz_engine.hip), writing  y0[t][r][c] = Y[t][r][0][c]  (dense [T][15 * 256]: the A operand of the K = 3840 GEMM)
+// and, for every needed (r, cnt >= 1) of the table,  dy[row][c] = Y[t][r][cnt][c] - Y[t][r][0][c]  at row = row_index[t][col].
+template <int P>
+__global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
+                                                      const float* __restrict__ bias, const float* __restrict__ acnt,
+                                                      float* __restrict__ y0, float* __restrict__ dy, int64_t dy_rows,
+                                                      const int32_t* __restrict__ pidx) {
+  const int c = threadIdx.x;
+  __shared__ float4 s_face[QF_TILE * P * 15];
+  const int64_t tb = (int64_t)blockIdx.x * QF_TILE;
+  const int nt = (int)(T - tb < QF_TILE ? T - tb : QF_TILE);
+  for (int i = threadIdx.x; i < nt * P * 15; i += QH) s_face[i] = face[tb * P * 15 + i];
+  __shared__ __attribute__((aligned(16))) int32_t s_pidx[QF_TILE * QP_COLS];
+  for (int i = threadIdx.x; i < nt * QP_COLS; i += QH) s_pidx[i] = pidx[tb * QP_COLS + i];
+  float w[P][10];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j <= k; ++j) w[p][q++] = wf[(int64_t)(p * 4 + j) * (4 * QH) + k * QH + c];
+  }
+  float b[4], a[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    b[k] = bias[k * QH + c];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) a[n][k] = acnt[((n + 1) * 4 + k) * QH + c];
+  }
+  __syncthreads();
+  const uint32_t nr = (uint32_t)dy_rows;
+  for (int ti = 0; ti < nt; ++ti) {   // table-major: a table's fifteen count-0 rows are one 15-KB run of y0
+    float* d0 = y0 + (tb + ti) * (15 * QH) + c;
+    for (int r = 0; r < 15; ++r) {
+      float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float4 x = s_face[(ti * P + p) * 15 + r];
+        s0 += w[p][0] * x.x;
+        s1 += w[p][1] * x.x + w[p][2] * x.y;
+        s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
+        s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+      }
+      const float v0 = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+      d0[r * QH] = v0;
+      int4 pr4 = make_int4(-1, -1, -1, -1);
+      if (r < 13) pr4 = *(const int4*)&s_pidx[ti * QP_COLS + 4 * r];
+      else pr4.x = s_pidx[ti * QP_COLS + 52 + (r - 13)];
+      // (unsigned compares: -1 and anything beyond the buffer are skipped alike; row_index is device data)
+      if ((uint32_t)pr4.x < nr) dy[(uint32_t)pr4.x * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[0][0], s1 + a[0][1]), fmaxf(s2 + a[0][2], s3 + a[0][3])) - v0;
+      if ((uint32_t)pr4.y < nr) dy[(uint32_t)pr4.y * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[1][0], s1 + a[1][1]), fmaxf(s2 + a[1][2], s3 + a[1][3])) - v0;
+      if ((uint32_t)pr4.z < nr) dy[(uint32_t)pr4.z * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[2][0], s1 + a[2][1]), fmaxf(s2 + a[2][2], s3 + a[2][3])) - v0;
+      if ((uint32_t)pr4.w < nr) dy[(uint32_t)pr4.w * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[3][0], s1 + a[3][1]), fmaxf(s2 + a[3][2], s3 + a[3][3])) - v0;
+    }
+  }
+}
+
+// ---- 3. fc1 on the matrix cores, exact f32 ---------------------------------------------------------------------------------
+// C[m][0..255] (+)= sum_k A[m][k] * B[k][0..255] with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered
+// fmaf chain; 64 cycles per instruction and SIMD = the fp32 vector peak, 157.3 TFLOP/s).  Block = 256 threads = 4 wavefronts,
+// tile = 128 rows x all 256 outputs (A is read from HBM once), wave w owns rows 32 w .. 32 w + 31 x 8 column tiles = 8
+// accumulators of 16 VGPRs.  K runs in chunks of FC_K = 16 through ONE LDS buffer (A 128 x 17, B 16 x 288 floats, padded so
+// that the operand reads are conflict-free: lane l reads A[l & 31][k + (l >> 5)] and B[k + (l >> 5)][32 n + (l & 31)]); the
+// global loads of chunk i + 1 are issued into registers before chunk i is multiplied and stored to LDS after it; inside a
+// chunk the operands of k-slice j + 1 are read from LDS before the eight MFMAs of slice j issue (209 VGPRs, 27 KB of LDS:
+// two blocks per CU cover each other's barriers).  (Chunks of 32 need 48 staging registers: the compiler then serialises
+// operand reads and MFMAs to stay under 256 VGPRs, or spills.)
+//   ROWS = false: the dense GEMM  H0 [M][256] += Y0 [M][K] x Wd [K][256]  (K = 3840: 240 chunks per tile; C holds the
+//                 per-table term on entry and is added in the epilogue).
+//   ROWS = true : D [row][256] = dY [row][256] x W2[rank of the row][256][256]: tile b belongs to the rank r with
+//                 seg[16 + r] <= b < seg[16 + r + 1] (device memory: nothing crosses to the host), tiles >= seg[31] exit.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // (native vectors: HIP's float4 struct arrays end up in scratch here)
+constexpr int FC_AS = FC_K + 1;      // LDS row stride of A (floats)
+constexpr int FC_BS = FC_N + 32;     // ... of B
+constexpr int FC_NA = FC_K / 8, FC_NB = FC_K / 4;   // float4 per thread and chunk: A 128 x FC_K floats, B FC_K x 256
+__device__ __forceinline__ void fc1_load(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t m0, int64_t M,
+                                         int k0, int tid, f32x4 (&ra)[FC_NA], f32x4 (&rb)[FC_NB]) {
+  // global -> registers: A row f / (FC_K / 4), k 4 (f % (FC_K / 4)); B row f / 64, columns 4 (f % 64)
+#pragma unroll
+  for (int i = 0; i < FC_NA; ++i) {
+    const int f = tid + 256 * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
+    const int64_t m = m0 + row < M ? m0 + row : M - 1;   // (rows beyond M: some valid row, never stored -- no branch)
+    ra[i] = *(const f32x4*)(A + m * lda + k0 + 4 * kq);
+  }
+#pragma unroll
+  for (int i = 0; i < FC_NB; ++i) {
+    const int f = tid + 256 * i, row = f >> 6, c4 = f & 63;
+    rb[i] = *(const f32x4*)(B + (int64_t)(k0 + row) * FC_N + 4 * c4);
+  }
+}
+__device__ __forceinline__ void fc1_stage(float* __restrict__ sA, float* __restrict__ sB, int tid, const f32x4 (&ra)[FC_NA],
+                                          const f32x4 (&rb)[FC_NB]) {
+#pragma unroll
+  for (int i = 0; i < FC_NA; ++i) {
+    const int f = tid + 256 * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
+    float* d = sA + row * FC_AS + 4 * kq;
+    d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+  }
+#pragma unroll
+  for (int i = 0; i < FC_NB; ++i) {
+    const int f = tid + 256 * i, row = f >> 6, c4 = f & 63;
+    *(f32x4*)(sB + row * FC_BS + 4 * c4) = rb[i];
+  }
+}
+__device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const float* __restrict__ pb, f32x16 (&acc)[8]) {
+  // the operands of k-slice kk + 2 are read from LDS before the eight MFMAs of slice kk are issued (explicit double buffer:
+  // an LDS read then has 8 x 64 cycles of matrix work to land in)
+  float a0 = pa[0], b0[8], a1 = 0.f, b1[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { b0[n] = pb[32 * n]; b1[n] = 0.f; }
+#pragma unroll
+  for (int kk = 0; kk < FC_K; kk += 4) {
+    a1 = pa[kk + 2];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) b1[n] = pb[(kk + 2) * FC_BS + 32 * n];
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads next to their MFMAs to save registers)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kk + 4 < FC_K) {
+      a0 = pa[kk + 4];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) b0[n] = pb[(kk + 4) * FC_BS + 32 * n];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <bool ROWS>
+__global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
+  __shared__ float sA[FC_M * FC_AS];
+  __shared__ __attribute__((aligned(16))) float sB[FC_K * FC_BS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * FC_M;
+  if (ROWS) {
+    if ((int)blockIdx.x >= seg[31]) return;
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < 15; ++q) r += (int)blockIdx.x >= seg[16 + q];
+    B += (int64_t)r * QH * FC_N;
+    M = seg[15];
+  }
+  f32x4 ra[FC_NA], rb[FC_NB];
+  fc1_load(A, lda, B, m0, M, 0, tid, ra, rb);
+  f32x16 acc[8];
+  const int crow = 4 * (lane >> 5), ccol = lane & 31;   // C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+  fc1_stage(sA, sB, tid, ra, rb);
+  __syncthreads();
+  const float* pa = sA + (32 * wv + (lane & 31)) * FC_AS + (lane >> 5);
+  const float* pb = sB + (lane >> 5) * FC_BS + (lane & 31);
+  for (int k0 = FC_K; k0 < K; k0 += FC_K) {   // chunk k0 - FC_K is in LDS; chunk k0 travels through the registers meanwhile
+    fc1_load(A, lda, B, m0, M, k0, tid, ra, rb);
+    fc1_chunk(pa, pb, acc);
+    __syncthreads();
+    fc1_stage(sA, sB, tid, ra, rb);
+    __syncthreads();
+  }
+  fc1_chunk(pa, pb, acc);
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t row = m0 + 32 * wv + (g & 3) + 8 * (g >> 2) + crow;
+      if (row < M) C[row * FC_N + 32 * n + ccol] = ROWS ? acc[n][g] : acc[n][g] + C[row * FC_N + 32 * n + ccol];
+    }
+}
+
+// ---- 4. the per-row stage over the needed rows -------------------------------------------------------------------------------
+// q[t][j] = b2 + w2 . relu( H0[t] + sum over the ranks r move j touches of ( D[row_index[t][col(r, cnt)]] + Z[r][cnt] ) )
+// One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4 l .. 4 l + 3; H0[t] is one coalesced
+// 1-KB read, a row adds one 1-KB read of D and one of Z per rank it touches (1.3 on average).  A column that is not set (a
+// list that does not belong to this row_index) or points beyond the buffer contributes nothing and raises status bit 5.
+__global__ __launch_bounds__(TB, 4) void k_q_slab_needed(const float4* __restrict__ H0, const float4* __restrict__ D, int64_t d_rows,
+                                                        const float4* __restrict__ Z, int64_t T, int tpw, const float4* __restrict__ w2,
+                                                        const float* __restrict__ b2, const int32_t* __restrict__ counts,
+                                                        const uint4* __restrict__ rows, int64_t stride, float* __restrict__ q,
+                                                        const int32_t* __restrict__ pidx, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int wv = (int)rfl(threadIdx.x >> 6);
+  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
+  const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
+  const float4 w = w2[lane];
+  const float bias = b2[0];
+  for (int i = 0; i < ntab; ++i) {
+    const int64_t t = t0 + i;
+    int n = (int)rfl((uint32_t)counts[t]);
+    if (n < 0 || n > stride) n = 0;
+    if (n == 0) continue;
+    const uint4* lrow = rows + t * stride;
+    float* qt = q + t * stride;
+    const int32_t myidx = pidx[t * QP_COLS + lane];
+    const float4 h0 = H0[t * (QH / 4) + lane];
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int m = n - j0 < 64 ? n - j0 : 64;
+      uint4 myrow = make_uint4(0, 0, 0, 0);
+      if (lane < m) myrow = lrow[j0 + lane];
+      const uint64_t mynib = pack_row(myrow);
+      float res = 0.f;
+      for (int jj = 0; jj < m; ++jj) {
+        const uint64_t nib = rl64(mynib, jj);  // wave-uniform
+        float4 h = h0;
+        for (uint32_t tm = ge_mask(nib, 1); tm; tm &= tm - 1) {
+          const int r = __builtin_ctz(tm);
+          uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
+          c = c > 4u ? 4u : c;
+          if (r >= 13 && c > 1u) c = 1u;
+          const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, qp_col(r, (int)c));
+          const float4 zz = Z[(r * 5 + (int)c) * (QH / 4) + lane];
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((uint32_t)pr < (uint32_t)d_rows) v = D[(int64_t)pr * (QH / 4) + lane];
+          else if (lane == 0) atomicOr(status, 32);
+          h.x += v.x + zz.x; h.y += v.y + zz.y; h.z += v.z + zz.z; h.w += v.w + zz.w;
+        }
+        float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
+        p = wave_sum_f32(p);
+        if (lane == jj) res = p + bias;
+      }
+      if (lane < m) qt[j0 + lane] = res;
+    }
+  }
+}

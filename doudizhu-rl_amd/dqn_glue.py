@@ -212,6 +212,7 @@ class FactorisedQ:
         self.base = (n.fc1.bias + torch.einsum("ocw,c->o", W1z, n.conv_shunzi.bias)).contiguous()
         W2 = W1y.permute(2, 1, 0).contiguous()                         # [r, c, o]: fc1 per rank
         self.W2 = W2
+        self.Wd = W2.reshape(15 * H, H1)                               # the dense GEMM's right operand: K = 15 * 256, rank-major
         # one GEMM batch per (rank, count): ranks 3..2 have counts 0..4 (65 batches), the two jokers counts 0..1
         self.W2_main = W2[:13, None].expand(13, 5, H, H1).reshape(65, H, H1).contiguous()
         self.W2_jok = [W2[r, None].expand(2, H, H1).contiguous() for r in (13, 14)]
@@ -359,6 +360,116 @@ class FactorisedQ:
         tab = torch.addmm(self.base, face.reshape(T, P * 60), self.Mz_f)
         return PackedU(Uc, row_index, row0, tab)
 
+    # ---- needed form: H0 per table from ONE dense GEMM + D only for the (rank, count) rows some legal move uses ----
+    @torch.no_grad()
+    def needed(self, env, face, gemm="mfma"):
+        """face f32 [T,P,15,4] of env's CURRENT states (its slab lists are read on the device) -> NeededU: h0 f32 [T,256],
+        d f32 [rows,256], row_index int32 [T,64], seg int32 [40] (device).  Nothing crosses to the host; every launch is
+        graph-capturable.  gemm = "mfma": both GEMMs by the engine's fp32 MFMA kernel (ddz_q_fc1_dense / _rows); "torch":
+        the dense one by torch.addmm (hipBLASLt), the rows by ddz_q_fc1_rows (a library GEMM would need the segment sizes
+        on the host).  The result aliases this object's workspace: consume it before the next call."""
+        from . import engine as E
+        if self._ver != self._versions():
+            self.refresh()
+        T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
+        if tuple(face.shape[1:]) != (P, 15, 4) or T != env.T or not face.is_cuda:
+            raise ValueError(f"face must be a device tensor [T,{P},15,4] of the environment's tables")
+        key = ("needed", face.device, T)
+        if key not in self._ws:
+            cap = (20 * T + 15 * 128 + 127) // 128 * 128               # a move takes at most what the actor holds: <= 20 cards
+            dev = face.device
+            self._ws[key] = {"cap": cap, "y0": torch.zeros((T, 15 * H), dtype=torch.float32, device=dev),
+                             "dy": torch.zeros((cap, H), dtype=torch.float32, device=dev),
+                             "d": torch.zeros((cap, H1), dtype=torch.float32, device=dev),
+                             "h0": torch.zeros((T, H1), dtype=torch.float32, device=dev),
+                             "row_index": torch.full((T, 64), -1, dtype=torch.int32, device=dev),
+                             "seg": torch.zeros(40, dtype=torch.int32, device=dev),
+                             "scratch": torch.zeros(E.q_need_scratch_bytes(T), dtype=torch.uint8, device=dev)}
+        w = self._ws[key]
+        env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"])
+        E.q_features_needed(face, self.Wf, self.bias_f, self.A, w["row_index"], w["y0"], w["dy"])
+        torch.addmm(self.base, face.view(T, P * 60), self.Mz_f, out=w["h0"])      # the per-table term (K = 60 P: small)
+        if gemm == "mfma":
+            E.q_fc1_dense(w["y0"], self.Wd, w["h0"])
+        elif gemm == "torch":
+            w["h0"].addmm_(w["y0"], self.Wd)
+        else:
+            raise ValueError("gemm must be 'mfma' or 'torch'")
+        E.q_fc1_rows(w["dy"], w["seg"], self.W2, w["d"])
+        return NeededU(w["h0"], w["d"], w["row_index"], w["seg"])
+
+    @staticmethod
+    def need_sets(rows, offsets, T):
+        """bool [T,15,4]: [t, r, c - 1] <=> some move of table t's CSR list takes exactly c cards of rank r (a joker exists
+        once: only c = 1)."""
+        N = rows.shape[0]
+        pos = torch.arange(N, device=rows.device, dtype=offsets.dtype)
+        seg = torch.searchsorted(offsets[1:].contiguous(), pos, right=True).clamp_(max=T - 1).long()
+        valid = pos < offsets[T]
+        cnt = rows[:, :15].long().clamp(0, 4)
+        cnt[:, 13:] = cnt[:, 13:].clamp(max=1)
+        hit = (cnt[:, :, None] == torch.arange(1, 5, device=rows.device)[None, None, :]) & valid[:, None, None]   # [N,15,4]
+        need = torch.zeros((T, 15, 4), dtype=torch.int32, device=rows.device)
+        need.index_add_(0, seg, hit.to(torch.int32))
+        return need > 0
+
+    @torch.no_grad()
+    def needed_torch(self, face, rows, offsets):
+        """The same in plain torch from CSR lists (any device): the statement the engine's needed-rows kernels are tested
+        against -- same row layout (rank segments from multiples of 128, inside a segment table-major then count), so
+        row_index and seg compare exactly."""
+        if self._ver != self._versions():
+            self.refresh()
+        T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
+        dev = face.device
+        need = self.need_sets(rows, offsets, T)                         # [T,15,4]
+        per_rank = need.permute(1, 0, 2).reshape(15, T * 4)             # rank-major; inside a rank (t, c) order
+        n_r = per_rank.sum(1)
+        seg = torch.zeros(40, dtype=torch.int32, device=dev)
+        row = 0
+        starts = []
+        for r in range(15):
+            starts.append(row)
+            seg[r], seg[16 + r] = row, row // 128
+            row += (int(n_r[r]) + 127) // 128 * 128
+        seg[15], seg[31], seg[32] = row, row // 128, int(n_r.sum())
+        excl = per_rank.long().cumsum(1) - per_rank.long()
+        idx = torch.where(per_rank, excl + torch.tensor(starts, device=dev)[:, None], -1).view(15, T, 4).permute(1, 0, 2)
+        row_index = torch.full((T, 64), -1, dtype=torch.int32, device=dev)
+        row_index[:, :52] = idx[:, :13].reshape(T, 52).to(torch.int32)
+        row_index[:, 52], row_index[:, 53] = idx[:, 13, 0].to(torch.int32), idx[:, 14, 0].to(torch.int32)
+        Y = self._first_layer_torch(face)                               # [15,5,T,H]
+        y0 = Y[:, 0].permute(1, 0, 2).reshape(T, 15 * H).contiguous()
+        dy = torch.zeros((max(row, 128), H), dtype=torch.float32, device=dev)
+        d = torch.zeros((max(row, 128), H1), dtype=torch.float32, device=dev)
+        for r in range(15):
+            for c in range(1, 5 if r < 13 else 2):
+                dst = idx[:, r, c - 1]
+                m = dst >= 0
+                dy[dst[m]] = Y[r, c][m] - Y[r, 0][m]
+            d[starts[r]: starts[r] + int(n_r[r])] = dy[starts[r]: starts[r] + int(n_r[r])] @ self.W2[r]
+        h0 = torch.addmm(self.base, face.reshape(T, P * 60), self.Mz_f) + y0 @ self.Wd
+        nu = NeededU(h0, d, row_index, seg)
+        nu.y0, nu.dy = y0, dy
+        return nu
+
+    @torch.no_grad()
+    def q_csr_needed(self, nu, rows, offsets):
+        """q of every CSR row from a NeededU (plain torch; the statement ddz_q_slab_needed is tested against)."""
+        T = nu.row_index.shape[0]
+        N = rows.shape[0]
+        pos = torch.arange(N, device=rows.device, dtype=offsets.dtype)
+        seg = torch.searchsorted(offsets[1:].contiguous(), pos, right=True).clamp_(max=T - 1).long()
+        cnt = rows[:, :15].long().clamp_(0, 4)
+        cnt[:, 13:] = cnt[:, 13:].clamp(max=1)
+        r = torch.arange(15, device=rows.device)
+        col = torch.where(r[None, :] < 13, 4 * r[None, :] + cnt - 1, 52 + (r[None, :] - 13)).clamp(min=0)
+        prow = nu.row_index.long()[seg[:, None], col]                   # [N,15]
+        use = (cnt > 0) & (prow >= 0)
+        dsum = (nu.d[prow.clamp(min=0)] * use[:, :, None]).sum(1)
+        h = nu.h0[seg] + dsum + F.embedding_bag(r[None, :] * 5 + cnt, self.Z.view(-1, self.H1), mode="sum")
+        return F.relu(h) @ self.w2 + self.b2
+
     def _first_layer_torch(self, face):
         T, P, H = face.shape[0], self.P, self.H
         X = face.permute(2, 0, 1, 3).reshape(15 * T, P * 4)
@@ -404,6 +515,8 @@ class FactorisedQ:
     def q_slab(self, env, U, out=None):
         """The per-row stage over the engine's slab lists (ddz_q_slab): q f32 [T, stride], entries beyond counts[t]
         untouched.  Feeds env.policy_step_slab / select_slab."""
+        if isinstance(U, NeededU):
+            return env.q_slab_needed(U.h0, U.d, U.row_index, self.Z, self.w2, self.b2, out=out)
         if isinstance(U, PackedU):
             return env.q_slab_packed(U.u, U.row_index, U.rank_row0, U.table_term, self.Z, self.w2, self.b2, out=out)
         return env.q_slab(U, self.Z, self.w2, self.b2, out=out)
@@ -418,6 +531,16 @@ class PackedU:
         self.u, self.row_index, self.rank_row0, self.table_term = u, row_index, rank_row0, table_term
 
 
+class NeededU:
+    """FactorisedQ.needed's result: h0 f32 [T,256] (fc1's pre-activation of the pass: every count 0), d f32 [rows,256] (what a
+    needed (rank, count >= 1) adds to it), row_index int32 [T,64], seg int32 [40] (device: segment starts, rows in use)."""
+    __slots__ = ("h0", "d", "row_index", "seg", "y0", "dy")
+
+    def __init__(self, h0, d, row_index, seg):
+        self.h0, self.d, self.row_index, self.seg = h0, d, row_index, seg
+        self.y0 = self.dy = None
+
+
 def ragged_q(net, face, rows, offsets):
     """Q(face_t, action) for every legal row of every table (dqn.py:56,67: policy_net(face, actions) for all tables at
     once): face f32 [T,P,15,4], rows int8 [N,16] + offsets int32 [T+1] in CSR order -> q f32 [N].  The factorised
@@ -430,31 +553,52 @@ def ragged_q(net, face, rows, offsets):
 
 class PolicyLoop:
     """game.py:95-104 for T tables with a Q-network on every seat, one lock-step iteration per step(), no per-table work on
-    the host (packed: one 128-byte copy per iteration; packed=False: nothing -- no .item(), no size-dependent allocation):
-        face -> FactorisedQ.tables (dense GEMMs) -> ddz_q_slab (q of every legal row, slab layout)
-             -> ddz_policy_step_slab (epsilon-greedy arg-max + apply + next lists + next face, ONE launch)."""
+    the host:
+        face -> Q of every legal move of every table (slab layout) -> ddz_policy_step_slab (epsilon-greedy arg-max + apply +
+        next lists + next face, ONE launch).
+    mode "needed" (default): FactorisedQ.needed -- the rows legal moves use, found on the device, both fc1 GEMMs on the
+        engine's fp32 MFMA kernel; nothing crosses to the host, every launch is graph-capturable (gemm="torch": the dense
+        GEMM by hipBLASLt instead);
+    mode "packed": round 3's form (15 + cards-in-hand rows per table, fifteen library GEMMs, one 128-byte device -> host copy
+        per iteration for their shapes); mode "full": all 69 rows per table, fixed shapes (packed=True / False select these)."""
 
-    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=True):
+    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=None, mode=None, gemm="mfma"):
         from .engine import FACE_PLANES
         if FACE_PLANES[face_variant] != net.planes:
             raise ValueError("the network's input planes do not match the face variant")
+        if mode is None:
+            mode = "needed" if packed is None else ("packed" if packed else "full")
+        if mode not in ("needed", "packed", "full"):
+            raise ValueError("mode must be 'needed', 'packed' or 'full'")
         self.env, self.fq = env, FactorisedQ(net)
         self.variant, self.epsilon, self.auto_reset = int(face_variant), float(epsilon), bool(auto_reset)
+        self.mode, self.gemm = mode, gemm
         T = env.T
         self.face = env.observe(self.variant)
-        # packed (default): the first layer and fc1 only for the (rank, count) rows the actors' hands allow -- a third of
-        # the work -- at the price of one 128-byte device -> host copy per iteration (the 15 GEMM shapes); packed=False:
-        # fixed shapes, nothing on the host
-        self.packed = bool(packed)
-        self.U = None if self.packed else torch.zeros((15, 5, T, self.fq.H1), dtype=torch.float32, device=env.device)
+        self.packed = mode == "packed"
+        self.U = torch.zeros((15, 5, T, self.fq.H1), dtype=torch.float32, device=env.device) if mode == "full" else None
         self.q = torch.zeros((T, env.slab_stride), dtype=torch.float32, device=env.device)
         self.choice = torch.empty(T, dtype=torch.int32, device=env.device)
         if not env._slab_fresh:
             env.legal_slab()
 
+    def describe(self):
+        if self.mode == "needed":
+            return ("ddz_q_need (the (rank, count) rows the legal moves use, on the device) -> ddz_q_features_needed (first "
+                    "layer: y0 per table + dY per needed row) -> ddz_q_fc1_dense (H0 = tab + y0 x Wd, K = 3840) + ddz_q_fc1_rows "
+                    "(D = dY x fc1[rank]) on the fp32 MFMA kernel k_fc1" + (" [dense GEMM: torch.addmm]" if self.gemm == "torch" else "")
+                    + " -> ddz_q_slab_needed -> ddz_policy_step_slab(greedy, face): every legal action of every table gets its Q "
+                    "value each iteration; nothing crosses to the host")
+        if self.mode == "packed":
+            return ("FactorisedQ.tables_packed [ddz_q_features_packed + one torch GEMM per rank over 15 + cards-in-hand rows per "
+                    "table] -> ddz_q_slab_packed -> ddz_policy_step_slab; one 128-byte device -> host copy per iteration")
+        return "FactorisedQ.tables (all 69 (rank, count) rows per table, fixed shapes) -> ddz_q_slab -> ddz_policy_step_slab"
+
     def q_values(self):
         """q [T, stride] of the current lists (valid in [:, :counts[t]])"""
-        if self.packed:
+        if self.mode == "needed":
+            return self.fq.q_slab(self.env, self.fq.needed(self.env, self.face, gemm=self.gemm), out=self.q)
+        if self.mode == "packed":
             return self.fq.q_slab(self.env, self.fq.tables_packed(self.face, self.env.actor_hands()), out=self.q)
         self.fq.tables(self.face, out=self.U)
         return self.fq.q_slab(self.env, self.U, out=self.q)
@@ -468,6 +612,77 @@ class PolicyLoop:
     def run(self, n):
         for _ in range(int(n)):
             self.step()
+
+    def profile(self, n=10):
+        """Per-stage device time of n iterations of the needed form (HIP events on the launching stream around every stage)
+        with each stage's algorithmic FLOP or bytes: {stage: {"us", "kernel", "flop" | "bytes", "note"}}.  Synchronises."""
+        from . import engine as E
+        if self.mode != "needed":
+            raise ValueError("profile() describes the needed form")
+        env, fq, T, P = self.env, self.fq, self.env.T, self.fq.P
+        w = None
+        names = ("need", "features", "table_term", "fc1_dense", "fc1_rows", "row_stage", "env_step")
+        ev = {k: [] for k in names}
+        rows_needed = rows_padded = moves = 0
+
+        def timed(name, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ev[name].append((a, b))
+
+        self.q_values()                                                   # (workspace exists)
+        w = fq._ws[("needed", self.face.device, T)]
+        for _ in range(int(n)):
+            timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"]))
+            timed("features", lambda: E.q_features_needed(self.face, fq.Wf, fq.bias_f, fq.A, w["row_index"], w["y0"], w["dy"]))
+            timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
+            if self.gemm == "mfma":
+                timed("fc1_dense", lambda: E.q_fc1_dense(w["y0"], fq.Wd, w["h0"]))
+            else:
+                timed("fc1_dense", lambda: w["h0"].addmm_(w["y0"], fq.Wd))
+            timed("fc1_rows", lambda: E.q_fc1_rows(w["dy"], w["seg"], fq.W2, w["d"]))
+            timed("row_stage", lambda: env.q_slab_needed(w["h0"], w["d"], w["row_index"], fq.Z, fq.w2, fq.b2, out=self.q))
+            seg = w["seg"].cpu()
+            rows_needed += int(seg[32]); rows_padded += int(seg[15]); moves += int(env.counts.sum())
+            timed("env_step", lambda: env.policy_step_slab(self.q, self.epsilon, face_variant=self.variant, face_out=self.face,
+                                                           choice_out=self.choice, auto_reset=self.auto_reset))
+        torch.cuda.synchronize(env.device)
+        us = {k: sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v) for k, v in ev.items()}
+        rn, rp, mv = rows_needed / n, rows_padded / n, moves / n
+        H = fq.H
+        return {
+            "need": {"us": us["need"], "kernel": "k_q_need_mask + k_q_need_scan + k_q_need_assign", "bytes": mv * 16 + T * (8 + 8 + 256),
+                     "note": "list rows read, need sets written and read, row_index written"},
+            "features": {"us": us["features"], "kernel": f"k_q_feat_needed<{P}>", "bytes": T * P * 240 + T * 15 * H * 4 + rn * H * 4 + T * 256,
+                         "note": "face + row_index read, y0 [T, 3840] + dY [needed rows, 256] written"},
+            "table_term": {"us": us["table_term"], "kernel": "torch.addmm (hipBLASLt)", "flop": 2.0 * T * P * 60 * H,
+                           "note": "fc1 bias + the face part of conv_shunzi: [T, 60 P] x [60 P, 256]"},
+            "fc1_dense": {"us": us["fc1_dense"], "kernel": "k_fc1<false>" if self.gemm == "mfma" else "torch.addmm (hipBLASLt)",
+                          "flop": 2.0 * T * 15 * H * H, "note": "H0 += y0 [T, 3840] x Wd [3840, 256]"},
+            "fc1_rows": {"us": us["fc1_rows"], "kernel": "k_fc1<true>", "flop": 2.0 * rn * H * H,
+                         "note": f"D = dY x fc1[rank]: {rn:.0f} needed rows per iteration ({rn / T:.2f} per table), {rp:.0f} computed "
+                                 "with the padding of the fifteen 128-row-aligned segments; FLOP of the needed rows"},
+            "row_stage": {"us": us["row_stage"], "kernel": "k_q_slab_needed", "bytes": T * H * 4 + rn * H * 4 + mv * 20,
+                          "note": "H0 + the needed D rows + the list rows read, q written"},
+            "env_step": {"us": us["env_step"], "kernel": "k_slab<4,true>", "bytes": T * (2 * 176 + P * 240 + 8) + mv * 24,
+                         "note": "arg-max over q, apply, new lists, new face"},
+        }
+
+    def variants(self, timed_loop, sync):
+        """env steps/s of the other forms of the same loop on the same environment (bench.py): the dense GEMM by hipBLASLt,
+        round 3's packed rows, fixed shapes."""
+        out = {}
+        T = self.env.T
+        for name, kw in (("needed_dense_gemm_by_hipblaslt", {"mode": "needed", "gemm": "torch"}),
+                         ("packed_rows_round3", {"mode": "packed"}), ("fixed_shapes", {"mode": "full"})):
+            loop = PolicyLoop(self.env, self.fq.net, face_variant=self.variant, epsilon=self.epsilon, **kw)
+            loop.run(2)
+            dt, reps = timed_loop(lambda: loop.run(5), sync, min_s=0.2, max_reps=64)
+            out[name + "_env_steps_per_s"] = T * 5 * reps / dt
+            del loop
+        return out
 
 
 class Replay:

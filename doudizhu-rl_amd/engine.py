@@ -299,6 +299,34 @@ class BatchedEnv:
                                          self._pp["counts"], self._pp["rows"], self.slab_stride, _p(out), _stream(self.device)))
         return out
 
+    # ---- the needed-rows form of the ragged Q forward (csrc/ddz_qnet.h; dqn_glue.FactorisedQ.needed) ----
+    def q_need(self, row_capacity, scratch, row_index, seg):
+        """ddz_q_need: which (rank, count >= 1) rows the CURRENT slab lists use, per table, laid out in rank segments:
+        writes row_index int32 [T,64] and seg int32 [40] (device); nothing crosses to the host."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        if (row_index.dtype != torch.int32 or tuple(row_index.shape) != (self.T, 64) or not row_index.is_contiguous()
+                or seg.dtype != torch.int32 or seg.numel() < 40 or scratch.dtype != torch.uint8):
+            raise ValueError("row_index must be int32 [T,64], seg int32 [40], scratch uint8")
+        check(self.lib.ddz_q_need(self._h, self._pp["counts"], self._pp["rows"], self.slab_stride, int(row_capacity),
+                                  _p(scratch), scratch.numel(), _p(row_index), _p(seg), _stream(self.device)))
+
+    def q_slab_needed(self, h0, d, row_index, z, w2, b2, out=None):
+        """ddz_q_slab_needed: q f32 [T, stride] of every legal move from h0 f32 [T,256], d f32 [rows,256], row_index."""
+        if not self._slab_fresh:
+            self.legal_slab()
+        H = int(h0.shape[-1])
+        for x, shp in ((h0, (self.T, H)), (d, (d.shape[0], H))):
+            if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != self.device:
+                raise ValueError("h0 must be float32 [T,hidden], d float32 [rows,hidden], contiguous, on the engine's device")
+        if out is None:
+            out = torch.zeros((self.T, self.slab_stride), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.numel() != self.T * self.slab_stride or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [T, stride] tensor")
+        check(self.lib.ddz_q_slab_needed(self._h, _p(h0), _p(d), int(d.shape[0]), _p(row_index), _p(z), H, _p(w2), _p(b2),
+                                         self._pp["counts"], self._pp["rows"], self.slab_stride, _p(out), _stream(self.device)))
+        return out
+
     def legal_onehot(self):
         """valid_actions(tensor=True) for all tables: f32 [sum A,15,4] (one host sync)."""
         self._need_legal()
@@ -552,6 +580,57 @@ def q_features_packed(face, wf, bias, acnt, row_index, rank_row0, y):
     check(L.ddz_q_features_packed(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(row_index), r0, n_rows, _p(y),
                                   int(y.shape[1]), _stream(dev)))
     return y
+
+
+def q_need_scratch_bytes(n_tables):
+    return int(_lib.lib().ddz_q_need_scratch_bytes(int(n_tables)))
+
+
+def q_features_needed(face, wf, bias, acnt, row_index, y0, dy):
+    """ddz_q_features_needed: first layer into y0 f32 [T, 15 * 256] (count 0 of every rank) and dy f32 [rows, 256]
+    (Y[count] - Y[0] at the row of every needed (table, rank, count): row_index from BatchedEnv.q_need)."""
+    L = _lib.lib()
+    dev = _require_gpu(face.device)
+    T, P = int(face.shape[0]), int(face.shape[1])
+    if face.dtype != torch.float32 or tuple(face.shape[2:]) != (15, 4) or not face.is_contiguous():
+        raise ValueError("face must be a contiguous float32 [T,P,15,4] tensor")
+    if y0.dtype != torch.float32 or tuple(y0.shape) != (T, 15 * 256) or not y0.is_contiguous() or y0.device != dev:
+        raise ValueError("y0 must be a contiguous float32 [T, 3840] tensor on the same device")
+    if dy.dtype != torch.float32 or dy.dim() != 2 or dy.shape[1] != 256 or not dy.is_contiguous() or dy.device != dev:
+        raise ValueError("dy must be a contiguous float32 [rows, 256] tensor on the same device")
+    if row_index.dtype != torch.int32 or tuple(row_index.shape) != (T, 64) or not row_index.is_contiguous() or row_index.device != dev:
+        raise ValueError("row_index must be a contiguous int32 [T,64] tensor on the same device")
+    for w, n in ((wf, P * 4 * 1024), (bias, 1024), (acnt, 5 * 4 * 256)):
+        if w.dtype != torch.float32 or w.numel() != n or not w.is_contiguous() or w.device != dev:
+            raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")
+    check(L.ddz_q_features_needed(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(row_index), _p(y0), _p(dy),
+                                  int(dy.shape[0]), _stream(dev)))
+
+
+def q_fc1_dense(a, w, c):
+    """ddz_q_fc1_dense: c f32 [n,256] += a f32 [n,k] @ w f32 [k,256] on the fp32 matrix cores (exact f32; k % 16 == 0)."""
+    L = _lib.lib()
+    dev = _require_gpu(a.device)
+    n, k = int(a.shape[0]), int(a.shape[1])
+    for x, shp in ((a, (n, k)), (w, (k, 256)), (c, (n, 256))):
+        if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != dev:
+            raise ValueError("a [n,k], w [k,256], c [n,256]: contiguous float32 tensors on one device")
+    check(L.ddz_q_fc1_dense(dev.index, _p(a), n, k, _p(w), _p(c), _stream(dev)))
+    return c
+
+
+def q_fc1_rows(dy, seg, w2, d):
+    """ddz_q_fc1_rows: d[row] = dy[row] @ w2[rank of the row] for the rows / rank segments of seg (device int32 [40])."""
+    L = _lib.lib()
+    dev = _require_gpu(dy.device)
+    n = int(dy.shape[0])
+    for x, shp in ((dy, (n, 256)), (d, (n, 256)), (w2, (15, 256, 256))):
+        if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != dev:
+            raise ValueError("dy / d [rows,256], w2 [15,256,256]: contiguous float32 tensors on one device")
+    if seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
+        raise ValueError("seg must be int32 [40] on the same device")
+    check(L.ddz_q_fc1_rows(dev.index, _p(dy), _p(seg), _p(w2), _p(d), n, _stream(dev)))
+    return d
 
 
 def action_table(device="cuda:0", native_joker_kickers=False):

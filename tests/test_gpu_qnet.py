@@ -1,0 +1,162 @@
+"""GPU (-m gpu): the needed-rows form of the ragged Q forward (csrc/ddz_qnet.h; BASELINE configs[2]) through the C ABI:
+the hand-written fp32 MFMA GEMM against exact integer products and an fp64 reference, the need sets / row layout bit for
+bit against the torch statement (dqn_glue.FactorisedQ.needed_torch), every stage's values against it and against the
+literal nn.Conv2d network (net.py:81-102; fp32, tolerance 1e-5 absolute on outputs of magnitude ~0.1: summation order
+only), and the whole PolicyLoop captured in a hipGraph."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("doudizhu-rl_amd")
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,K", [(128, 16), (300, 256), (1000, 3840), (129, 48)])
+def test_fc1_dense_is_an_exact_f32_gemm(pkg, M, K):
+    """ddz_q_fc1_dense (k_fc1: v_mfma_f32_32x32x2_f32).  Integer-valued operands whose products and sums are exact in fp32:
+    the result must EQUAL the integer product (an asymmetric B, rows beyond the last full tile, C added in); random fp32
+    operands: every element within 2e-6 * sum |a b| of the fp64 product (a k-ordered fmaf chain)."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (K, 256), generator=g).float()
+    w[:, 1::3] += torch.arange(K).float()[:, None] % 5                     # asymmetric, column-dependent
+    c0 = torch.randint(-50, 50, (M, 256), generator=g).float()
+    c = c0.clone().to(_dev())
+    pkg.q_fc1_dense(a.to(_dev()), w.to(_dev()), c)
+    want = c0.double() + a.double() @ w.double()
+    assert float(want.abs().max()) < 2 ** 23
+    assert torch.equal(c.cpu().double(), want)
+    a = torch.randn((M, K), generator=g)
+    w = torch.randn((K, 256), generator=g)
+    c = torch.zeros((M, 256), device=_dev())
+    pkg.q_fc1_dense(a.to(_dev()), w.to(_dev()), c)
+    want = a.double() @ w.double()
+    bound = 2e-6 * (a.abs().double() @ w.abs().double()) + 1e-30
+    assert bool(((c.cpu().double() - want).abs() <= bound).all())
+    with pytest.raises(pkg.DdzError):
+        pkg.q_fc1_dense(torch.zeros((M, 24), device=_dev()), torch.zeros((24, 256), device=_dev()), c)   # K % 16 != 0
+
+
+def _csr_of_slab(env):
+    off, rows, _ = env.slab_to_csr(rows_per_table=512)
+    n = int(off[-1])
+    return off.clone(), rows[:max(n, 1)].clone(), n
+
+
+@pytest.mark.parametrize("P,variant", [(6, 3), (4, 0), (9, 2)])
+def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, variant):
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    T = 700                                                  # not a multiple of the 16 / 128 / 256 tile sizes
+    torch.manual_seed(3 + P)
+    net = glue.QNet(P).to(_dev()).eval()
+    net_cpu = copy.deepcopy(net).cpu()
+    env = pkg.BatchedEnv(T, seed=11 + P, device=_dev())
+    env.reset()
+    fq = glue.FactorisedQ(net)
+    fqc = glue.FactorisedQ(net_cpu)
+    for rounds in (0, 9, 23):                                # fresh deals (20-card leads), then mixed states
+        env.rollout_random(rounds) if rounds else None
+        env.legal_slab()
+        face = env.observe(variant)
+        nu = fq.needed(env, face)
+        w = fq._ws[("needed", face.device, T)]
+        off, rows, n = _csr_of_slab(env)
+        ref = fqc.needed_torch(face.cpu(), rows.cpu(), off.cpu())
+        # layout: bit for bit
+        assert torch.equal(nu.row_index.cpu(), ref.row_index)
+        assert nu.seg.cpu()[:34].tolist() == ref.seg[:34].tolist() and int(nu.seg[33]) == 0
+        used = int(ref.seg[15])
+        needed = ref.row_index >= 0
+        rows_used = ref.row_index[needed].long()
+        # values: first layer, the two GEMMs, the row stage
+        assert float((w["y0"].cpu() - ref.y0).abs().max()) < 2e-6
+        assert float((w["dy"].cpu()[rows_used] - ref.dy[rows_used]).abs().max()) < 2e-6
+        assert float((nu.h0.cpu() - ref.h0).abs().max()) < 1e-5
+        assert float((nu.d.cpu()[rows_used] - ref.d[rows_used]).abs().max()) < 1e-5
+        q = fq.q_slab(env, nu)
+        counts = env.counts.long()
+        valid = torch.arange(env.slab_stride, device=_dev())[None, :] < counts[:, None]
+        q_csr = q[valid].cpu()                                # slab order == CSR order
+        qt = fqc.q_csr_needed(ref, rows.cpu(), off.cpu())[:n]
+        assert q_csr.numel() == n and float((q_csr - qt).abs().max()) < 1e-5
+        seg_t = torch.repeat_interleave(torch.arange(T), counts.cpu())
+        pick = torch.arange(0, n, 5)
+        acts = (rows.cpu()[pick, :15].float()[:, :, None] > torch.arange(4)[None, None, :]).float()
+        with torch.no_grad():
+            want = net_cpu(face.cpu()[seg_t[pick]], acts)[:, 0]
+        assert float((q_csr[pick] - want).abs().max()) < 1e-5
+        assert used % 128 == 0 and used <= w["cap"]
+        # the dense GEMM by the library gives the same H0 up to summation order
+        nu2 = fq.needed(env, face, gemm="torch")
+        assert float((nu2.h0.cpu() - ref.h0).abs().max()) < 1e-5
+    assert env.status() == 0
+    # a row_index that does not belong to the lists: nothing is dereferenced beyond the buffers, status bit 5
+    wild = nu.row_index.clone()
+    wild[wild >= 0] += w["cap"]
+    qw = env.q_slab_needed(nu.h0, nu.d, wild, fq.Z, fq.w2, fq.b2)
+    assert bool(torch.isfinite(qw[valid]).all()) and env.status() & 32
+
+
+def test_need_capacity_overflow_is_flagged_not_written(pkg):
+    """row_capacity too small for the needed rows: status bit 1, seg[33] = 1, the rows that do not fit are -1 (never an
+    index beyond the capacity); a capacity that is no multiple of 128 is an argument error."""
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    engine = importlib.import_module("doudizhu-rl_amd.engine")
+    T = 512
+    env = pkg.BatchedEnv(T, seed=5, device=_dev())
+    env.reset(); env.legal_slab()                            # 20-card leads: ~20 needed rows per table
+    cap = 15 * 128 + 1024
+    row_index = torch.full((T, 64), -1, dtype=torch.int32, device=_dev())
+    seg = torch.zeros(40, dtype=torch.int32, device=_dev())
+    scratch = torch.zeros(engine.q_need_scratch_bytes(T), dtype=torch.uint8, device=_dev())
+    env.q_need(cap, scratch, row_index, seg)
+    s = seg.cpu().tolist()
+    assert s[33] == 1 and s[15] <= cap and s[32] > cap and int(row_index.max()) < cap
+    assert env.status() & 2
+    with pytest.raises(pkg.DdzError):
+        env.q_need(cap + 5, scratch, row_index, seg)
+    assert glue is not None
+
+
+def test_policy_loop_needed_form_is_graph_capturable(pkg):
+    """PolicyLoop.step in the needed form has no host synchronisation (no .cpu(), no size-dependent shape): 6 iterations
+    captured in a hipGraph and replayed 3 times == the same 18 iterations issued one by one (states, faces, choices and
+    q values bit for bit), with either implementation of the dense GEMM."""
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    for gemm in ("mfma", "torch"):
+        T, K = 1500, 6
+        torch.manual_seed(1)
+        net = glue.QNet(6).to(_dev()).eval()
+        a = pkg.BatchedEnv(T, seed=21, device=_dev())
+        b = pkg.BatchedEnv(T, seed=21, device=_dev())
+        a.reset(); b.reset()
+        la = glue.PolicyLoop(a, net, face_variant=3, epsilon=0.1, gemm=gemm)
+        lb = glue.PolicyLoop(b, net, face_variant=3, epsilon=0.1, gemm=gemm)
+        la.run(2); lb.run(2)                                 # workspaces allocated, libraries warm
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                la.run(K)
+        torch.cuda.current_stream().wait_stream(s)
+        for _ in range(3):
+            g.replay()
+            lb.run(K)
+        torch.cuda.synchronize()
+        assert torch.equal(a.state, b.state) and torch.equal(la.face, lb.face) and torch.equal(la.choice, lb.choice)
+        valid = torch.arange(a.slab_stride, device=_dev())[None, :] < a.counts.long()[:, None]
+        assert torch.equal(a.counts, b.counts) and torch.equal(la.q[valid], lb.q[valid])
+        assert a.status() == 0 and a.stats() == b.stats()
