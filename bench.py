@@ -198,10 +198,15 @@ def rollout_leg(pkg, torch, dev, T, pmc_key):
            "roofline": hbm_block("k_rollout", (260 + 16 * mean_a) * steps / n, dur, launches_timed=n,
                                  env_steps_per_launch=steps / n, algorithmic_bytes_per_env_step=260 + 16 * mean_a,
                                  issue=issue_block(pmc_key, steps / n, dur))}
-    env.rollout_random_csr(20)
-    dtc, repc = timed_loop(lambda: env.rollout_random_csr(50), sync)
-    out["csr_env_steps_per_s"] = T * 50 * repc / dtc
-    out["csr_us_per_iteration"] = dtc / (50 * repc) * 1e6
+    env.rollout_random_csr(64)
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(256), sync)
+    out["csr_env_steps_per_s"] = T * 256 * repc / dtc
+    out["csr_us_per_iteration"] = dtc / (256 * repc) * 1e6
+    env.rollout_random_csr(20, batch=0)
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(50, batch=0), sync)
+    out["csr_launch_per_iteration_env_steps_per_s"] = T * 50 * repc / dtc
+    out["csr_note"] = ("packed CSR lists every iteration: batches of iterations staged by one rollout launch + two compaction "
+                       "launches (ddz_rollout_random_csr_staged); csr_launch_per_iteration: round 3's form")
     assert env.status() == 0
     return out
 
@@ -685,11 +690,14 @@ def main():
     ach = b_launch / dur_launch / 1e9
 
     # ---- the same loop with packed CSR lists (one launch per iteration): a number, not the headline
-    env.rollout_random_csr(20)
+    env.rollout_random_csr(64)
     torch.cuda.synchronize(dev)
-    dtc, repc = timed_loop(lambda: env.rollout_random_csr(50), lambda: torch.cuda.synchronize(dev))
-    csr_rate = T * 50 * repc / dtc
-    csr_us = dtc / (50 * repc) * 1e6
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(256), lambda: torch.cuda.synchronize(dev))
+    csr_rate = T * 256 * repc / dtc
+    csr_us = dtc / (256 * repc) * 1e6
+    env.rollout_random_csr(10, batch=0)
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(20, batch=0), lambda: torch.cuda.synchronize(dev))
+    csr_rate_per_launch = T * 20 * repc / dtc
 
     if rank == 0:
         out = {
@@ -707,8 +715,11 @@ def main():
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
                        "list_layout": "slab (fixed-stride segment per table)",
                        "csr_env_steps_per_s": csr_rate, "csr_us_per_iteration": csr_us,
+                       "csr_launch_per_iteration_env_steps_per_s": csr_rate_per_launch,
                        "csr_note": "the same loop with packed CSR lists (offsets / rows as ddz_legal writes them: SURVEY 8(d) "
-                                   "config 2 'outputs = CSR legal list only') beside the slab layout of `value`",
+                                   "config 2 'outputs = CSR legal list only') beside the slab layout of `value`: batches of "
+                                   "iterations staged by one rollout launch, compacted by two more "
+                                   "(ddz_rollout_random_csr_staged); csr_launch_per_iteration: round 3's form",
                        "per_rank_env_steps_per_s": per_rank,
                        "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

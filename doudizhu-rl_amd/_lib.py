@@ -48,6 +48,9 @@ SYMBOLS = {
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddz_rollout_random_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_void_p]),
+    "ddz_rollout_csr_staging_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "ddz_rollout_random_csr_staged": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_rollout_random_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "ddz_read_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

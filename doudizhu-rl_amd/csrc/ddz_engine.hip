@@ -879,6 +879,8 @@ struct RolloutArgs {
   uint4* rows;       // [T][stride] list slabs
   int32_t* ids;      // [T][stride] or null
   int64_t stride;
+  int64_t it_rows;   // staged form (ddz_rollout_random_csr_staged): iteration j of the launch writes its lists into slab j --
+  int64_t it_counts; // rows / ids advance by it_rows, counts by it_counts per iteration (0, 0: every iteration overwrites slab 0)
   int64_t n_iters;   // lock-step iterations run inside this launch
   uint4* traj;       // [n_iters][T][2] or null
   int64_t* wave_stats;
@@ -949,7 +951,11 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     uint32_t draws = 0, dnext = 64;  // lane dnext holds the next draw; 64 = refill
     uint4* tj = TRAJ ? a.traj + 2 * t : nullptr;  // record of (iteration, table)
     if (!active) {  // frozen table (never dealt / finished without auto-reset): empty lists, flagged records
-      if (lane == 0) a.counts[t] = 0;
+      if (lane == 0) {
+        a.counts[t] = 0;
+        if (a.it_counts)
+          for (int64_t j = 1; j < a.n_iters; ++j) a.counts[t + j * a.it_counts] = 0;
+      }
       if (TRAJ) {
         const uint4 f0 = make_uint4(0, 0, 0, 0);
         const uint4 f1 = make_uint4((uint32_t)role | ((mx >> 8) & 0xFF) << 8 | 2u << 24, ply << 16, episode, 0xFFFFFFFFu);
@@ -973,7 +979,9 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       // rfl: the combo to beat stays wave-uniform for the compiler, so the category dispatch below is
       // scalar branches (the carried state itself lives in VGPRs: measured faster than on the scalar unit)
       const uint32_t info = rfl((passes >= 2) ? mk_info(EMPTY, 0, 1) : trick);
-      const int64_t base = t * a.stride;
+      const int64_t jn = a.n_iters - it;                      // iteration of this launch (staged form: its slab)
+      const int64_t base = t * a.stride + jn * a.it_rows;
+      int32_t* const cnt_p = a.counts + t + jn * a.it_counts;
       const uint32_t draw = rl(draws, (int)dnext);
       stamps.mark(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
       int n = 0, idx = -1;
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           if (IDS) a.ids[base + pre] = lane == 0 ? 0 : lane < 16 ? (lc0 == SINGLE ? 1 : lc0 == DOUBLE ? 16 : lc0 == TRIPLE ? 29 : 42) + rr
                                       : lane < 29 ? 42 + rr : ID_BIGBANG;
         }
-        a.counts[t] = n;  // every lane stores the same word: no exec-mask change
+        *cnt_p = n;  // every lane stores the same word: no exec-mask change
         s_rows += n;
         stamps.mark(5);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
@@ -1030,7 +1038,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
           n = 0;
         }
         stamps.mark(2);  // scan (planner + rounds + staging)
-        a.counts[t] = n;
+        *cnt_p = n;
         s_rows += n;
         for (int j = lane; j < n; j += 64) {  // flush: coalesced 16-byte rows
           const uint64_t e = stage[j];
@@ -1698,8 +1706,15 @@ __global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ 
 // consumes) -- the "prefix-sum compaction of the variable-length legal-action list" as its own cheap pass, so that the
 // stepping kernels never wait on a scan over all tables.  Two launches: sizes -> block scans, then offsets + row copy.
 constexpr int CSR_BT = 256;  // tables per block
+// blockIdx.y = one of several slabs compacted by the same launch (ddz_rollout_random_csr_staged: the iterations of a batch;
+// CsrBatch = how far the buffers advance per slab; all zero for a single slab)
+struct CsrBatch { int64_t counts, rows, scan, blk; int first; };
 __global__ __launch_bounds__(CSR_BT) void k_csr_scan(const int32_t* __restrict__ counts, int64_t n, int64_t stride,
-                                                     int32_t* __restrict__ local_off, int32_t* __restrict__ blk_tot) {
+                                                     int32_t* __restrict__ local_off, int32_t* __restrict__ blk_tot, CsrBatch bt) {
+  {
+    const int64_t y = bt.first + (int64_t)blockIdx.y;
+    counts += y * bt.counts; local_off += y * bt.scan; blk_tot += y * bt.blk;
+  }
   __shared__ int sh[CSR_BT / 64];
   const int64_t t = (int64_t)blockIdx.x * CSR_BT + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1723,7 +1738,13 @@ __global__ __launch_bounds__(CSR_BT) void k_csr_copy(const int32_t* __restrict__
                                                      const int32_t* __restrict__ ids, int64_t n, int64_t stride,
                                                      const int32_t* __restrict__ local_off, const int32_t* __restrict__ blk_tot,
                                                      int32_t* __restrict__ offsets, uint4* __restrict__ rows_out,
-                                                     int32_t* __restrict__ ids_out, int64_t cap, int32_t* __restrict__ status) {
+                                                     int32_t* __restrict__ ids_out, int64_t cap, int32_t* __restrict__ status,
+                                                     CsrBatch bt) {
+  {
+    const int64_t y = bt.first + (int64_t)blockIdx.y;
+    counts += y * bt.counts; rows += y * bt.rows; local_off += y * bt.scan; blk_tot += y * bt.blk;
+    if (IDS) ids += y * bt.rows;
+  }
   __shared__ long long sh[CSR_BT / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   long long part = 0;
@@ -2861,15 +2882,16 @@ int ddz_slab_to_csr(ddz_env_t* e, const int32_t* counts, const int8_t* rows, con
   hipStream_t st = (hipStream_t)stream;
   const int64_t nb = (e->T + CSR_BT - 1) / CSR_BT;  // <= lay.nblk = ceil(T / 4)
   e->counts_valid = false;                             // the scan buffers of the CSR path are reused here
-  hipLaunchKernelGGL(k_csr_scan, dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, e->T, stride, e->sc.local_off[0], e->sc.blk_tot[0]);
+  hipLaunchKernelGGL(k_csr_scan, dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, e->T, stride, e->sc.local_off[0], e->sc.blk_tot[0],
+                     CsrBatch{});
   int rc = check_launch();
   if (rc) return rc;
   if (ids_out)
     hipLaunchKernelGGL((k_csr_copy<true>), dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, (const uint4*)rows, ids, e->T, stride,
-                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status);
+                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status, CsrBatch{});
   else
     hipLaunchKernelGGL((k_csr_copy<false>), dim3((unsigned)nb), dim3(CSR_BT), 0, st, counts, (const uint4*)rows, ids, e->T, stride,
-                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status);
+                       e->sc.local_off[0], e->sc.blk_tot[0], offsets, (uint4*)rows_out, ids_out, row_capacity, e->sc.status, CsrBatch{});
   return check_launch();
 }
 
@@ -2884,11 +2906,12 @@ int ddz_read_stats(ddz_env_t* e, int64_t* stats, void* stream) {
 }
 
 static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* rows, int32_t* ids, int64_t stride,
-                          uint8_t* traj, hipStream_t st) {
+                          uint8_t* traj, hipStream_t st, int64_t it_rows = 0, int64_t it_counts = 0) {
   RolloutArgs a;
   a.state = e->state; a.T = e->T; a.tpw = e->tpw;
   a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32); a.gid_base = e->gid_base;
   a.counts = counts; a.rows = (uint4*)rows; a.ids = ids; a.stride = stride;
+  a.it_rows = it_rows; a.it_counts = it_counts;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
   const dim3 grid((unsigned)e->nblocks), block(TB);
   // the kernel counts iterations and plies in 32 bits: at most 2^20 iterations per launch (about a second)
@@ -2944,6 +2967,72 @@ int ddz_rollout_random_csr(ddz_env_t* e, int64_t n_iters, int32_t* offsets, int8
     rc = launch_table<F_ENUM | F_STEP, DDZ_STEP_RANDOM>(e, io, st);  // CSR needs the scan of the previous launch
     if (rc) return rc;
   }
+  return DDZ_OK;
+}
+
+// The CSR rollout without a launch per iteration: the lists of a BATCH of iterations are staged as slabs by ONE k_rollout
+// launch (state in registers, no table waits for another one), then compacted to CSR by one k_csr_scan + one k_csr_copy
+// launch over (blocks x iterations of the batch) -- the cross-table prefix of an iteration is computed after the fact, so
+// it is nobody's launch boundary.  Every iteration's lists are written to offsets / rows / ids at their CSR positions as
+// ddz_legal would write them; the last iteration of the call is compacted by a launch of its own behind all the others, so
+// the buffers end up holding exactly its lists (earlier iterations of a batch are written concurrently).
+int64_t ddz_rollout_csr_staging_bytes(int64_t n_tables, int batch, int want_ids) {
+  if (n_tables <= 0 || batch < 1) return 0;
+  const int64_t nb = (n_tables + CSR_BT - 1) / CSR_BT;
+  int64_t o = 0;
+  o = align_up(o + (int64_t)batch * n_tables * 4, 256);                        // counts
+  o = align_up(o + (int64_t)batch * n_tables * 4, 256);                        // local offsets
+  o = align_up(o + (int64_t)batch * nb * 4, 256);                              // block totals
+  o = align_up(o + (int64_t)batch * n_tables * DDZ_SLAB_MIN_STRIDE * 16, 256); // rows
+  if (want_ids) o = align_up(o + (int64_t)batch * n_tables * DDZ_SLAB_MIN_STRIDE * 4, 256);
+  return o;
+}
+
+int ddz_rollout_random_csr_staged(ddz_env_t* e, int64_t n_iters, int batch, void* staging, int64_t staging_bytes, int32_t* offsets,
+                                  int8_t* rows, int32_t* ids, int64_t cap, uint8_t* traj, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!al(rows, 16) || !al(offsets, 4) || !al(ids, 4) || !al(traj, 16) || !al(staging, 256)) return DDZ_EINVAL;
+  if (n_iters < 0 || batch < 1 || !staging || !offsets || !rows || cap < 0) return DDZ_EINVAL;
+  if (cap > 0x7FFFFFFF || (int64_t)batch * e->T * DDZ_SLAB_MIN_STRIDE > 0x7FFFFFFF) return DDZ_ECAP;
+  if (staging_bytes < ddz_rollout_csr_staging_bytes(e->T, batch, ids != nullptr)) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t T = e->T, nb = (T + CSR_BT - 1) / CSR_BT, S = DDZ_SLAB_MIN_STRIDE;
+  uint8_t* p = (uint8_t*)staging;
+  int64_t o = 0;
+  int32_t* s_counts = (int32_t*)(p + o);   o = align_up(o + (int64_t)batch * T * 4, 256);
+  int32_t* s_local = (int32_t*)(p + o);    o = align_up(o + (int64_t)batch * T * 4, 256);
+  int32_t* s_blk = (int32_t*)(p + o);      o = align_up(o + (int64_t)batch * nb * 4, 256);
+  int8_t* s_rows = (int8_t*)(p + o);       o = align_up(o + (int64_t)batch * T * S * 16, 256);
+  int32_t* s_ids = ids ? (int32_t*)(p + o) : nullptr;
+  const CsrBatch bt0{T, T * S, T, nb, 0};
+  auto copy = [&](int first, int count) {
+    CsrBatch bt = bt0;
+    bt.first = first;
+    const dim3 grid((unsigned)nb, (unsigned)count);
+    if (ids)
+      hipLaunchKernelGGL((k_csr_copy<true>), grid, dim3(CSR_BT), 0, st, (const int32_t*)s_counts, (const uint4*)s_rows, (const int32_t*)s_ids,
+                         T, S, (const int32_t*)s_local, (const int32_t*)s_blk, offsets, (uint4*)rows, ids, cap, e->sc.status, bt);
+    else
+      hipLaunchKernelGGL((k_csr_copy<false>), grid, dim3(CSR_BT), 0, st, (const int32_t*)s_counts, (const uint4*)s_rows, (const int32_t*)s_ids,
+                         T, S, (const int32_t*)s_local, (const int32_t*)s_blk, offsets, (uint4*)rows, ids, cap, e->sc.status, bt);
+  };
+  for (int64_t done = 0; done < n_iters; done += batch) {
+    const int b = (int)(n_iters - done < batch ? n_iters - done : batch);
+    int rc = launch_rollout(e, b, s_counts, s_rows, s_ids, S, traj ? traj + done * T * DDZ_TRAJ_BYTES : nullptr, st, T * S, T);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_csr_scan, dim3((unsigned)nb, (unsigned)b), dim3(CSR_BT), 0, st, (const int32_t*)s_counts, T, S, s_local, s_blk, bt0);
+    const bool last = done + b >= n_iters;
+    if (!last) copy(0, b);
+    else {
+      if (b > 1) copy(0, b - 1);
+      copy(b - 1, 1);             // the call's last iteration: alone, behind everything else -- its lists are what stays
+    }
+    rc = check_launch();
+    if (rc) return rc;
+  }
+  e->legal_cap = cap;
   return DDZ_OK;
 }
 
@@ -3191,9 +3280,9 @@ int ddz_q_need(ddz_env_t* e, const int32_t* counts, const int8_t* rows, int64_t 
   const int64_t nblk = (e->T + QN_TPB - 1) / QN_TPB;
   uint64_t* need = (uint64_t*)scratch;
   int32_t* blk = (int32_t*)((uint8_t*)scratch + align_up(8 * e->T, 256));
-  hipLaunchKernelGGL(k_q_need_mask, dim3((unsigned)nblk), dim3(QN_TPB), 0, st, counts, (const uint4*)rows, stride, e->T, need, blk);
+  hipLaunchKernelGGL(k_q_need_mask, dim3((unsigned)nblk), dim3(256), 0, st, counts, (const uint4*)rows, stride, e->T, need, blk);
   hipLaunchKernelGGL(k_q_need_scan, dim3(1), dim3(256), 0, st, blk, nblk, seg, row_capacity);
-  hipLaunchKernelGGL(k_q_need_assign, dim3((unsigned)nblk), dim3(QN_TPB), 0, st, (const uint64_t*)need, e->T, (const int32_t*)blk,
+  hipLaunchKernelGGL(k_q_need_assign, dim3((unsigned)nblk), dim3(256), 0, st, (const uint64_t*)need, e->T, (const int32_t*)blk,
                      (const int32_t*)seg, row_index, e->sc.status);
   return check_launch();
 }

@@ -19,7 +19,7 @@
 // ---- 1. which rows are needed: three small launches, deterministic layout ---------------------------------------------
 // need[t] = 64-bit set over the columns of row_index (QP_COLS: (r < 13, c = 1..4) at 4 r + c - 1, the jokers' count 1 at
 // 52 / 53): column set <=> some legal move of table t takes exactly c cards of rank r.
-constexpr int QN_TPB = 256;          // tables per block of the need kernels (one thread per table)
+constexpr int QN_TPB = 64;           // tables per block of the need kernels (four lanes per table)
 constexpr int QN_SEG_WORDS = 40;     // seg[0..15] first row of rank r's segment (multiples of FC_M), [15] = rows in use,
                                      // seg[16..31] first TILE of rank r, [31] = tiles in use, seg[32] = rows needed, [33] = overflow
 constexpr int FC_M = 128, FC_K = 16, FC_N = 256;   // k_fc1's tile: 128 rows x all 256 fc1 outputs, K in chunks of 16
@@ -34,8 +34,8 @@ __device__ __forceinline__ uint64_t q_need_of_row(uint64_t nib) {
   out |= (uint64_t)(((nib >> 56) & 15u) != 0) << 53;
   return out;
 }
-// per-rank row counts of a need set, packed: 15 fields of 12 bits in three words (5 ranks each; a block of 256 tables sums to
-// at most 1024 per rank)
+// per-rank row counts of a need set, packed: 15 fields of 12 bits in three words (5 ranks each; a block of 64 tables sums to
+// at most 256 per rank)
 __device__ __forceinline__ void q_need_counts(uint64_t need, uint64_t w[3]) {
   w[0] = w[1] = w[2] = 0;
 #pragma unroll
@@ -46,25 +46,37 @@ __device__ __forceinline__ void q_need_counts(uint64_t need, uint64_t w[3]) {
 }
 __device__ __forceinline__ uint32_t q_need_field(const uint64_t w[3], int r) { return (uint32_t)(w[r / 5] >> (12 * (r % 5))) & 0xFFFu; }
 
-// (a) one thread per table: OR over the table's slab list -> need[t]; per block the per-rank row counts -> blk[b][16]
-__global__ __launch_bounds__(QN_TPB) void k_q_need_mask(const int32_t* __restrict__ counts, const uint4* __restrict__ rows,
-                                                        int64_t stride, int64_t T, uint64_t* __restrict__ need,
-                                                        int32_t* __restrict__ blk) {
-  const int64_t t = (int64_t)blockIdx.x * QN_TPB + threadIdx.x;
+// (a) four lanes per table (a wave = 16 tables, a block = 64): lane q of a table ORs rows q, q + 4, ... of its slab list (the
+// four 16-byte loads of a quad are one 64-byte run), two DPP steps join the quad -> need[t]; per block the per-rank row
+// counts -> blk[b][16]
+__device__ __forceinline__ uint64_t quad_or(uint64_t v) {   // OR over the 4 lanes of a quad, the result in all four
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo |= (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  hi |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xB1, 0xf, 0xf, false);
+  lo |= (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  hi |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x4E, 0xf, 0xf, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__global__ __launch_bounds__(256) void k_q_need_mask(const int32_t* __restrict__ counts, const uint4* __restrict__ rows,
+                                                     int64_t stride, int64_t T, uint64_t* __restrict__ need,
+                                                     int32_t* __restrict__ blk) {
+  const int q = threadIdx.x & 3;
+  const int64_t t = (int64_t)blockIdx.x * QN_TPB + (threadIdx.x >> 2);
   uint64_t m = 0;
   if (t < T) {
     int n = counts[t];
     if (n < 0 || n > stride) n = 0;
     const uint4* lr = rows + t * stride;
-    for (int j = 0; j < n; ++j) m |= q_need_of_row(pack_row(lr[j]));
-    need[t] = m;
+    for (int j = q; j < n; j += 4) m |= q_need_of_row(pack_row(lr[j]));
   }
+  m = quad_or(m);
+  if (t < T && q == 0) need[t] = m;
   uint64_t w[3];
-  q_need_counts(m, w);
-  __shared__ uint64_t s[3][QN_TPB / 64];
+  q_need_counts(q == 0 ? m : 0, w);   // (one lane per table counts)
+  __shared__ uint64_t s[3][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {  // wave sum of the packed fields (no field overflows: <= 64 * 4 per wave)
+  for (int k = 0; k < 3; ++k) {  // wave sum of the packed fields (no field overflows: <= 16 * 4 per wave)
     uint64_t v = w[k];
     for (int d = 32; d > 0; d >>= 1) v += ((uint64_t)__shfl_xor((uint32_t)(v >> 32), d) << 32) | (uint64_t)__shfl_xor((uint32_t)v, d);
     if (lane == 0) s[k][wv] = v;
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(QN_TPB) void k_q_need_mask(const int32_t* __restric
   if (threadIdx.x < 16) {
     uint64_t tot[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k)
-      for (int q = 0; q < QN_TPB / 64; ++q) tot[k] += s[k][q];
+      for (int i = 0; i < 4; ++i) tot[k] += s[k][i];
     blk[(int64_t)blockIdx.x * 16 + threadIdx.x] = threadIdx.x < 15 ? (int32_t)q_need_field(tot, (int)threadIdx.x) : 0;
   }
 }
@@ -95,10 +107,18 @@ __global__ __launch_bounds__(256) void k_q_need_scan(int32_t* __restrict__ blk, 
 #pragma unroll
   for (int r = 0; r < 15; ++r) s_part[tid][r] = acc[r];
   __syncthreads();
-  if (tid < 15) {  // exclusive scan over the 256 partials of rank tid
-    int32_t run = 0;
-    for (int i = 0; i < 256; ++i) { const int32_t v = s_part[i][tid]; s_part[i][tid] = run; run += v; }
-    s_tot[tid] = run;
+  {  // exclusive scan over the 256 partials of every rank: wave w scans ranks 4 w .. 4 w + 3, 64 lanes x 4 partials each
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int r = 4 * wv; r < 4 * wv + 4 && r < 15; ++r) {
+      int32_t v[4], sum = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = s_part[4 * lane + i][r]; sum += v[i]; }
+      const int32_t inc = wave_scan_add(sum);
+      int32_t run = inc - sum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s_part[4 * lane + i][r] = run; run += v[i]; }
+      if (lane == 63) s_tot[r] = inc;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -124,21 +144,23 @@ __global__ __launch_bounds__(256) void k_q_need_scan(int32_t* __restrict__ blk, 
   }
 }
 
-// (c) one thread per table: row of every needed (r, c) = seg[r] + rows of rank r in the blocks before + in the tables before
-// inside the block + position inside the table (ascending c); row_index[t][64], -1 = not needed.
-__global__ __launch_bounds__(QN_TPB) void k_q_need_assign(const uint64_t* __restrict__ need, int64_t T, const int32_t* __restrict__ blk,
-                                                          const int32_t* __restrict__ seg, int32_t* __restrict__ row_index,
-                                                          int32_t* __restrict__ status) {
-  const int64_t t = (int64_t)blockIdx.x * QN_TPB + threadIdx.x;
+// (c) four lanes per table: row of every needed (r, c) = seg[r] + rows of rank r in the blocks before + in the tables before
+// inside the block + position inside the table (ascending c); lane q of a table writes columns 16 q .. 16 q + 15 of
+// row_index[t][64] (-1 = not needed): a wave stores 16 tables x 256 bytes = one 4-KB run.
+__global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restrict__ need, int64_t T, const int32_t* __restrict__ blk,
+                                                       const int32_t* __restrict__ seg, int32_t* __restrict__ row_index,
+                                                       int32_t* __restrict__ status) {
+  const int q = threadIdx.x & 3;
+  const int64_t t = (int64_t)blockIdx.x * QN_TPB + (threadIdx.x >> 2);
   const uint64_t m = t < T ? need[t] : 0;
   uint64_t w[3], inc[3];
-  q_need_counts(m, w);
+  q_need_counts(m, w);                 // (the same in the four lanes of a table)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __shared__ uint64_t s[3][QN_TPB / 64];
+  __shared__ uint64_t s[3][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {  // inclusive wave scan of the packed fields
+  for (int k = 0; k < 3; ++k) {  // inclusive scan over the wave's 16 tables (quads): shifts by 4, 8, 16, 32 lanes
     uint64_t v = w[k];
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 4; d < 64; d <<= 1) {
       const uint64_t o = ((uint64_t)__shfl_up((uint32_t)(v >> 32), d) << 32) | (uint64_t)__shfl_up((uint32_t)v, d);
       if (lane >= d) v += o;
     }
@@ -150,29 +172,36 @@ __global__ __launch_bounds__(QN_TPB) void k_q_need_assign(const uint64_t* __rest
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     uint64_t before = 0;
-    for (int q = 0; q < wv; ++q) before += s[k][q];
+    for (int i = 0; i < wv; ++i) before += s[k][i];
     ex[k] = before + inc[k] - w[k];
   }
   if (t >= T) return;
-  int32_t out[QP_COLS];
+  int32_t out[16];
 #pragma unroll
-  for (int i = 0; i < QP_COLS; ++i) out[i] = -1;
+  for (int i = 0; i < 16; ++i) out[i] = -1;
   bool dropped = false;
 #pragma unroll
-  for (int r = 0; r < 15; ++r) {
-    const int32_t lo = seg[r], hi = seg[r + 1];   // (seg[15] = the end of rank 14's segment)
-    int32_t row = lo + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
+  for (int i = 0; i < 4; ++i) {        // lane q: ranks 4 q .. 4 q + 3 (q = 3: rank 12, then the two jokers' single columns)
+    const int r = 4 * q + i;
     if (r < 13) {
+      const int32_t hi = seg[r + 1];
+      int32_t row = seg[r] + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if ((m >> (4 * r + c)) & 1u) { if (row < hi) out[4 * r + c] = row; else dropped = true; ++row; }
-    } else if ((m >> (52 + r - 13)) & 1u) {
-      if (row < hi) out[52 + r - 13] = row; else dropped = true;
+        if ((m >> (4 * r + c)) & 1u) { if (row < hi) out[4 * i + c] = row; else dropped = true; ++row; }
     }
   }
-  int4* dst = (int4*)(row_index + t * QP_COLS);
+  if (q == 3) {
 #pragma unroll
-  for (int i = 0; i < QP_COLS / 4; ++i) dst[i] = make_int4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    for (int r = 13; r < 15; ++r)
+      if ((m >> (52 + r - 13)) & 1u) {
+        const int32_t row = seg[r] + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
+        if (row < seg[r + 1]) out[4 + r - 13] = row; else dropped = true;
+      }
+  }
+  int4* dst = (int4*)(row_index + t * QP_COLS + 16 * q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i] = make_int4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
   if (dropped) atomicOr(status, 2);   // row capacity overflow (cannot happen with capacity >= 20 T + 15 * 128)
 }
 
@@ -355,19 +384,26 @@ __global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int
 
 // ---- 4. the per-row stage over the needed rows -------------------------------------------------------------------------------
 // q[t][j] = b2 + w2 . relu( H0[t] + sum over the ranks r move j touches of ( D[row_index[t][col(r, cnt)]] + Z[r][cnt] ) )
-// One wavefront per table (tpw consecutive tables per wave), lane l owns hidden units 4 l .. 4 l + 3; H0[t] is one coalesced
-// 1-KB read, a row adds one 1-KB read of D and one of Z per rank it touches (1.3 on average).  A column that is not set (a
-// list that does not belong to this row_index) or points beyond the buffer contributes nothing and raises status bit 5.
+// One wavefront per table at a time (tpw consecutive tables per wave); the wave's four 16-lane rows work on FOUR MOVES at
+// once: lane l of a row owns hidden units {4 (l + 16 k) .. + 3, k = 0..3} (a 1-KB row of H0 / D / Z is four coalesced 256-byte
+// reads per 16 lanes), a move's dot product is reduced with four DPP row steps.  Z (75 KB, weights only) lives in LDS.  A
+// column that is not set (a list that does not belong to this row_index) or points beyond the buffer contributes nothing
+// and raises status bit 5.  (First version: one move per wave at a time, Z from L2: 409 us at 65,536 tables.)
 __global__ __launch_bounds__(TB, 4) void k_q_slab_needed(const float4* __restrict__ H0, const float4* __restrict__ D, int64_t d_rows,
                                                         const float4* __restrict__ Z, int64_t T, int tpw, const float4* __restrict__ w2,
                                                         const float* __restrict__ b2, const int32_t* __restrict__ counts,
                                                         const uint4* __restrict__ rows, int64_t stride, float* __restrict__ q,
                                                         const int32_t* __restrict__ pidx, int32_t* __restrict__ status) {
-  const int lane = threadIdx.x & 63;
+  __shared__ float4 sZ[75 * (QH / 4)];
+  for (int i = threadIdx.x; i < 75 * (QH / 4); i += TB) sZ[i] = Z[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l16 = lane & 15, quarter = lane >> 4;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
   const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
-  const float4 w = w2[lane];
+  float4 w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = w2[l16 + 16 * k];
   const float bias = b2[0];
   for (int i = 0; i < ntab; ++i) {
     const int64_t t = t0 + i;
@@ -376,34 +412,56 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab_needed(const float4* __restric
     if (n == 0) continue;
     const uint4* lrow = rows + t * stride;
     float* qt = q + t * stride;
-    const int32_t myidx = pidx[t * QP_COLS + lane];
-    const float4 h0 = H0[t * (QH / 4) + lane];
-    for (int j0 = 0; j0 < n; j0 += 64) {
-      const int m = n - j0 < 64 ? n - j0 : 64;
-      uint4 myrow = make_uint4(0, 0, 0, 0);
-      if (lane < m) myrow = lrow[j0 + lane];
-      const uint64_t mynib = pack_row(myrow);
-      float res = 0.f;
-      for (int jj = 0; jj < m; ++jj) {
-        const uint64_t nib = rl64(mynib, jj);  // wave-uniform
-        float4 h = h0;
-        for (uint32_t tm = ge_mask(nib, 1); tm; tm &= tm - 1) {
-          const int r = __builtin_ctz(tm);
-          uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
-          c = c > 4u ? 4u : c;
-          if (r >= 13 && c > 1u) c = 1u;
-          const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, qp_col(r, (int)c));
-          const float4 zz = Z[(r * 5 + (int)c) * (QH / 4) + lane];
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((uint32_t)pr < (uint32_t)d_rows) v = D[(int64_t)pr * (QH / 4) + lane];
-          else if (lane == 0) atomicOr(status, 32);
-          h.x += v.x + zz.x; h.y += v.y + zz.y; h.z += v.z + zz.z; h.w += v.w + zz.w;
+    const int32_t myidx = pidx[t * QP_COLS + lane];     // lane L holds column L of the table's row_index
+    float4 h0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h0[k] = H0[t * (QH / 4) + l16 + 16 * k];
+    for (int j0 = 0; j0 < n; j0 += 4) {
+      const int j = j0 + quarter;
+      const bool have = j < n;
+      const uint64_t nib = have ? pack_row(lrow[j]) : 0;   // (the 16 lanes of a row read the same 16 bytes)
+      float4 h[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h[k] = h0[k];
+      uint32_t tm = ge_mask(nib, 1);                        // the ranks this row's move touches
+      while (__ballot(tm != 0)) {                           // wave-uniform trip count: the row with the most ranks
+        const bool act = tm != 0;
+        const int r = act ? __builtin_ctz(tm) : 0;
+        uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
+        c = c > 4u ? 4u : c;
+        if (r >= 13 && c > 1u) c = 1u;
+        const int col = act ? qp_col(r, (int)c) : 63;       // (column 63 is never set)
+        const int32_t pr = __shfl(myidx, col);              // every lane active here
+        if (act) {
+          const float4* zr = sZ + (r * 5 + (int)c) * (QH / 4) + l16;
+          if ((uint32_t)pr < (uint32_t)d_rows) {
+            const float4* dr = D + (int64_t)pr * (QH / 4) + l16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4 v = dr[16 * k], zz = zr[16 * k];
+              h[k].x += v.x + zz.x; h[k].y += v.y + zz.y; h[k].z += v.z + zz.z; h[k].w += v.w + zz.w;
+            }
+          } else {
+            if (l16 == 0) atomicOr(status, 32);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4 zz = zr[16 * k];
+              h[k].x += zz.x; h[k].y += zz.y; h[k].z += zz.z; h[k].w += zz.w;
+            }
+          }
         }
-        float p = fmaxf(h.x, 0.f) * w.x + fmaxf(h.y, 0.f) * w.y + fmaxf(h.z, 0.f) * w.z + fmaxf(h.w, 0.f) * w.w;
-        p = wave_sum_f32(p);
-        if (lane == jj) res = p + bias;
+        tm &= tm - 1;
       }
-      if (lane < m) qt[j0 + lane] = res;
+      float p = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        p += fmaxf(h[k].x, 0.f) * w[k].x + fmaxf(h[k].y, 0.f) * w[k].y + fmaxf(h[k].z, 0.f) * w[k].z + fmaxf(h[k].w, 0.f) * w[k].w;
+      // sum over the 16 lanes of the row: four DPP row shifts, the total lands in lane 15 of the row
+      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x111, 0xf));
+      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x112, 0xf));
+      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x114, 0xf));
+      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x118, 0xf));
+      if (have && l16 == 15) qt[j] = p + bias;
     }
   }
 }

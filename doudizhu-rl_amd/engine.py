@@ -467,15 +467,30 @@ class BatchedEnv:
                                           _stream(self.device)))
         self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
-    def rollout_random_csr(self, n_iters, traj=None):
-        """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them); one
-        launch per iteration because CSR bases depend on every table.  Same states and
-        trajectories as rollout_random."""
+    def rollout_random_csr(self, n_iters, traj=None, batch=None):
+        """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them: afterwards they hold the lists
+        of the last iteration's pre-step states).  Same states and trajectories as rollout_random.
+        batch (default: as many iterations as ~2 GiB of staging hold, at most 32): the lists of a batch of iterations are
+        staged as slabs by ONE rollout launch and compacted to CSR by two more (ddz_rollout_random_csr_staged) -- no launch
+        per iteration; batch=0: the one-launch-per-iteration form (ddz_rollout_random_csr: CSR bases depend on every
+        table, so each iteration waits for the scan of the one before)."""
         if traj is not None and (traj.dtype != torch.uint8 or not traj.is_contiguous()
                                  or traj.numel() != n_iters * self.T * TRAJ_BYTES):
             raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
-        check(self.lib.ddz_rollout_random_csr(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
-                                              _p(self.ids), self.cap, _p(traj), _stream(self.device)))
+        if batch is None:
+            per = self.T * MAX_LEGAL_PER_TABLE * (20 if self.ids is not None else 16)
+            batch = max(2, min(32, (2 << 30) // per))
+        if batch:
+            batch = int(min(batch, max(1, n_iters)))
+            need = self.lib.ddz_rollout_csr_staging_bytes(self.T, batch, int(self.ids is not None))
+            if getattr(self, "_staging", None) is None or self._staging.numel() < need:
+                self._staging = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(self.lib.ddz_rollout_random_csr_staged(self._h, int(n_iters), batch, _p(self._staging), self._staging.numel(),
+                                                         _p(self.offsets), _p(self.rows), _p(self.ids), self.cap, _p(traj),
+                                                         _stream(self.device)))
+        else:
+            check(self.lib.ddz_rollout_random_csr(self._h, int(n_iters), _p(self.offsets), _p(self.rows),
+                                                  _p(self.ids), self.cap, _p(traj), _stream(self.device)))
         self._legal_fresh = self._slab_fresh = self._csr_fresh = False
 
     def rollout_random_timed(self, n_iters):

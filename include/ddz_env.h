@@ -210,6 +210,15 @@ int ddz_rollout_random(ddz_env_t* env, int64_t n_iters, int32_t* counts, int8_t*
  * states as ddz_rollout_random; after the call offsets/rows hold the last pre-step lists.     */
 int ddz_rollout_random_csr(ddz_env_t* env, int64_t n_iters, int32_t* offsets, int8_t* rows,
                            int32_t* ids, int64_t row_capacity, uint8_t* traj, void* stream);
+/* The same loop, same outputs (offsets / rows / ids hold the CSR lists of the last iteration's pre-step states, exactly as
+ * ddz_legal writes them; every iteration's lists are written there at their CSR positions), WITHOUT a launch per iteration:
+ * the lists of `batch` iterations are staged as slabs by one rollout launch and compacted by two more (the cross-table
+ * prefix of an iteration is nobody's launch boundary).  staging: caller-owned device scratch of
+ * ddz_rollout_csr_staging_bytes(n_tables, batch, ids != NULL) bytes (batch x n_tables x 512 rows of 16 (+ 4) bytes: size
+ * the batch for the memory you have), 256-byte aligned.  Same states, trajectories and RNG draws as ddz_rollout_random.  */
+int64_t ddz_rollout_csr_staging_bytes(int64_t n_tables, int batch, int want_ids);
+int ddz_rollout_random_csr_staged(ddz_env_t* env, int64_t n_iters, int batch, void* staging, int64_t staging_bytes,
+                                  int32_t* offsets, int8_t* rows, int32_t* ids, int64_t row_capacity, uint8_t* traj, void* stream);
 
 /* Measurement aid: the same loop between two hipEvents on `stream`.  ms (HOST, double[2])
  * receives {elapsed ms of the launch, n_iters}; synchronises the stream.

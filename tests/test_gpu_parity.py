@@ -220,15 +220,18 @@ def test_ragged_table_counts(pkg, oracle, T):
     assert env.status() == 0 and env2.status() == 0
 
 
-def test_rollout_csr_equals_slab_rollout(pkg, oracle):
-    """the CSR-list variant of the fused rollout: same trajectories and states as the slab one,
-    and its last lists are the oracle's CSR lists"""
+@pytest.mark.parametrize("batch,want_ids", [(None, True), (0, True), (7, True), (1, True), (64, False)])
+def test_rollout_csr_equals_slab_rollout(pkg, oracle, batch, want_ids):
+    """the CSR-list variants of the fused rollout -- staged batches compacted by two launches per batch (the default; batch
+    sizes that divide the iteration count, that do not, and that exceed it), and one launch per iteration (batch 0): same
+    trajectories and states as the slab rollout, and the lists left in offsets / rows / ids are byte for byte the oracle's
+    CSR lists of the last iteration's pre-step states"""
     T, n = 1500, 60
-    a = pkg.BatchedEnv(T, seed=31); b = pkg.BatchedEnv(T, seed=31); ref = oracle.OracleEnv(T, seed=31)
+    a = pkg.BatchedEnv(T, seed=31, want_ids=want_ids); b = pkg.BatchedEnv(T, seed=31, want_ids=want_ids); ref = oracle.OracleEnv(T, seed=31)
     a.reset(); b.reset(); ref.reset()
     ta = torch.zeros((n, T, 32), dtype=torch.uint8, device=_dev()); tb = torch.zeros_like(ta)
     a.rollout_random(n, traj=ta)
-    b.rollout_random_csr(n, traj=tb)
+    b.rollout_random_csr(n, traj=tb, batch=batch)
     assert torch.equal(ta, tb) and torch.equal(a.state, b.state)
     for _ in range(n - 1):
         ref.legal(); ref.step(oracle.STEP_RANDOM)
@@ -236,8 +239,11 @@ def test_rollout_csr_equals_slab_rollout(pkg, oracle):
     ref.step(oracle.STEP_RANDOM)
     m = int(roff[-1])
     assert np.array_equal(b.offsets.cpu().numpy(), roff)
-    assert np.array_equal(b.rows[:m].cpu().numpy(), rrows) and np.array_equal(b.ids[:m].cpu().numpy(), rids)
+    assert np.array_equal(b.rows[:m].cpu().numpy(), rrows) and (not want_ids or np.array_equal(b.ids[:m].cpu().numpy(), rids))
     assert np.array_equal(b.state.cpu().numpy(), ref.state) and b.status() == 0
+    # a second call continues from the new states (a staging buffer that is reused, frozen tables included)
+    b.rollout_random_csr(5, batch=batch); a.rollout_random(5)
+    assert torch.equal(a.state, b.state)
 
 
 def test_no_auto_reset_freezes_tables(pkg, oracle):
@@ -928,39 +934,61 @@ def test_misaligned_buffers_are_argument_errors(pkg):
 
 
 def test_bench_contract():
-    """bench.py prints ONE JSON line with the driver's keys, the roofline object (HIP-event launch duration, PMC
-    traffic) and, at N = 1, the CPU baseline."""
+    """bench.py prints ONE JSON line with the driver's keys; the N = 1 workload is the largest single-GPU configuration
+    (65,536 tables, the same per-GPU workload as N > 1); the headline roofline (HIP-event launch duration; replayed
+    inputs named with their source files) and one roofline block per leg; the CPU baseline; an empty `errors` list."""
     import json
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "300", "--warmup", "30",
-                        "--cpu-budget", "1.5"], capture_output=True, text=True, timeout=300)
+                        "--cpu-budget", "1.5"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "errors"):
         assert k in j, k
+    assert j["errors"] == []
     assert j["n_gpus"] == 1 and j["steps"] == 300 and j["warmup"] == 30 and j["higher_is_better"] is True
     assert j["unit"] == "env steps/s" and j["dtype"] == "u8" and j["scaling"] == "weak" and j["vs_baseline"] is None
-    assert j["value"] > 1e8 and abs(j["ms_per_step"] * 1e-3 * j["value"] - 4096) < 1
+    assert j["config"]["tables_per_gpu"] == 65536 and "65536 tables" in j["config"]["workload"]
+    assert j["value"] > 1e8 and abs(j["ms_per_step"] * 1e-3 * j["value"] - 65536) < 16
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
-    assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 4096 * j["iterations_per_launch"]
+    assert r["kernel"] == "k_rollout" and r["env_steps_per_launch"] == 65536 * j["iterations_per_launch"]
+    assert r["traffic"] is None or "profiles/pmc_traffic.json" in r["traffic_source"]          # replayed inputs say so
     assert "workload" in j["config"] and "model" not in j["config"]
     # self-sufficient timing: the 300-iteration launch is repeated until >= 50 ms are timed (VERDICT r01 item 2)
     assert j["timed_steps"] == 300 * j["repeats_of_the_steps_launch"] and j["timed_seconds"] >= 0.045
     assert j["iterations_per_launch"] == 1200   # four times the 300 steps: a launch carries >= 1000 iterations
     assert r["launches_timed"] >= 2 and r["launch_us"] * r["launches_timed"] >= 45e3
-    assert isinstance(j["config"]["csr_env_steps_per_s"], float) and j["config"]["csr_env_steps_per_s"] > 1e7
-    assert r["issue"] is None or (r["issue"]["bound"] == "valu-issue" and 0 < r["issue"]["frac"] < 1)
+    # the CSR layout beside the slab layout, at the same table count
+    assert j["config"]["csr_env_steps_per_s"] > 1e8 and j["config"]["csr_launch_per_iteration_env_steps_per_s"] > 1e7
+    assert j["config"]["per_rank_env_steps_per_s"] == [j["value"]]
+    iss = r["issue"]
+    assert iss is None or (iss["bound"] == "valu-issue" and 0 < iss["frac"] < 1 and "profiles/" in " ".join(iss["sources"].values())
+                           and iss["live"] == ["launch_us", "achieved", "frac"])
     legs = j["configs"]
-    for k in ("tables_65536_random_rollout", "tables_65536_policy_loop_slab", "tables_65536_policy_loop_fused", "tables_65536_step_slab_only",
+    for k in ("tables_4096_random_rollout", "tables_65536_traj_write_pack", "tables_65536_policy_loop_slab",
+              "tables_65536_policy_loop_fused", "tables_65536_dqn_inference", "tables_65536_step_slab_only",
               "tables_65536_step_slab_csr_lists", "tables_65536_rule_opponent"):
-        assert legs[k]["env_steps_per_s"] > 1e6, (k, legs)
+        assert legs[k]["env_steps_per_s"] > 1e6, (k, legs[k])
+        rf = legs[k]["roofline"]                                  # every leg carries the roof of its dominant kernel
+        assert rf["bound"] in ("hbm", "mfma") and rf["peak"] in (8000.0, 157.3) and 0 < rf["frac"] < 1 and rf["launch_us"] > 0, k
+    small = legs["tables_4096_random_rollout"]                    # configs[1] as BASELINE.json writes it
+    assert small["roofline"]["env_steps_per_launch"] == 4096 * 1000 and small["csr_env_steps_per_s"] > 1e8
+    for k in ("tables_65536_step_slab_only", "tables_65536_rule_opponent", "tables_65536_policy_loop_fused"):
+        iss = legs[k]["roofline"]["issue"]
+        assert iss is None or (iss["bound"] == "valu-issue" and iss["frac"] > 0)
+    dq = legs["tables_65536_dqn_inference"]
+    assert dq["roofline"]["bound"] == "mfma" and dq["roofline"]["dtype"] == "f32" and dq["env_steps_per_s"] > 5e6
+    st = dq["roofline"]["stages"]
+    assert {"need", "features", "table_term", "fc1_dense", "fc1_rows", "row_stage", "env_step"} <= set(st)
+    assert st["fc1_dense"]["bound"] == "mfma" and st["fc1_dense"]["kernel"] == "k_fc1<false>" and st["features"]["bound"] == "hbm"
+    assert abs(sum(dq["stages_us"].values()) - dq["us_per_iteration"]) < 0.25 * dq["us_per_iteration"]
     ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
     assert ret["up"] == ret["down"] == -ret["lord"] / 2 and ret["lord"] < -50  # rule farmers beat a random lord
     c = j["cpu_baseline"]
