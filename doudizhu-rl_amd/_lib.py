@@ -84,6 +84,7 @@ SYMBOLS = {
     "ddz_debug_set_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ddz_debug_set_auto_teams": (C.c_int, [C.c_void_p, C.c_int]),
     "ddz_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddz_sync": (C.c_int, [C.c_int, C.c_void_p]),
     "ddz_device_status": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "ddz_debug_classify": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

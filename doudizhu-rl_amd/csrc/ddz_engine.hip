@@ -888,7 +888,9 @@ struct RolloutArgs {
   int64_t* legal_rows;
 };
 
-template <bool IDS, bool TRAJ>
+// STAGED (ddz_rollout_random_csr_staged): iteration j of the launch writes its lists into slab j (a template parameter: the
+// per-iteration address arithmetic costs the plain rollout 12 % when it is a run-time option).
+template <bool IDS, bool TRAJ, bool STAGED = false>
 __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
   Stamps<12> stamps;
   __shared__ HotTabT<false> hot;
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
     if (!active) {  // frozen table (never dealt / finished without auto-reset): empty lists, flagged records
       if (lane == 0) {
         a.counts[t] = 0;
-        if (a.it_counts)
+        if (STAGED)
           for (int64_t j = 1; j < a.n_iters; ++j) a.counts[t + j * a.it_counts] = 0;
       }
       if (TRAJ) {
@@ -979,9 +981,9 @@ __global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
       // rfl: the combo to beat stays wave-uniform for the compiler, so the category dispatch below is
       // scalar branches (the carried state itself lives in VGPRs: measured faster than on the scalar unit)
       const uint32_t info = rfl((passes >= 2) ? mk_info(EMPTY, 0, 1) : trick);
-      const int64_t jn = a.n_iters - it;                      // iteration of this launch (staged form: its slab)
-      const int64_t base = t * a.stride + jn * a.it_rows;
-      int32_t* const cnt_p = a.counts + t + jn * a.it_counts;
+      const int64_t jn = STAGED ? a.n_iters - it : 0;         // iteration of this launch (staged form: its slab)
+      const int64_t base = t * a.stride + (STAGED ? jn * a.it_rows : 0);
+      int32_t* const cnt_p = a.counts + t + (STAGED ? jn * a.it_counts : 0);
       const uint32_t draw = rl(draws, (int)dnext);
       stamps.mark(1);  // per-iteration setup: frozen check, draw refresh, hand/info select
       int n = 0, idx = -1;
@@ -2919,7 +2921,12 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
   for (int64_t done = 0; done < n_iters; done += CHUNK) {
     a.n_iters = n_iters - done < CHUNK ? n_iters - done : CHUNK;
     a.traj = traj ? (uint4*)(traj + done * e->T * DDZ_TRAJ_BYTES) : nullptr;
-    if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true>), grid, block, 0, st, a);
+    if (it_rows) {
+      if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true, true>), grid, block, 0, st, a);
+      else if (ids) hipLaunchKernelGGL((k_rollout<true, false, true>), grid, block, 0, st, a);
+      else if (traj) hipLaunchKernelGGL((k_rollout<false, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((k_rollout<false, false, true>), grid, block, 0, st, a);
+    } else if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true>), grid, block, 0, st, a);
     else if (ids) hipLaunchKernelGGL((k_rollout<true, false>), grid, block, 0, st, a);
     else if (traj) hipLaunchKernelGGL((k_rollout<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_rollout<false, false>), grid, block, 0, st, a);
@@ -3158,6 +3165,13 @@ int ddz_status(ddz_env_t* e, int32_t* out, void* stream) {
   hipError_t r = hipMemcpyAsync(out, e->sc.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (r != hipSuccess) return hip_fail(r);
   r = hipStreamSynchronize((hipStream_t)stream);
+  return r == hipSuccess ? DDZ_OK : hip_fail(r);
+}
+
+int ddz_sync(int device, void* stream) {
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  const hipError_t r = hipStreamSynchronize((hipStream_t)stream);
   return r == hipSuccess ? DDZ_OK : hip_fail(r);
 }
 

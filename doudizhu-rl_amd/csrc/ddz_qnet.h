@@ -268,11 +268,11 @@ __global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__
 // C[m][0..255] (+)= sum_k A[m][k] * B[k][0..255] with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered
 // fmaf chain; 64 cycles per instruction and SIMD = the fp32 vector peak, 157.3 TFLOP/s).  Block = 256 threads = 4 wavefronts,
 // tile = 128 rows x all 256 outputs (A is read from HBM once), wave w owns rows 32 w .. 32 w + 31 x 8 column tiles = 8
-// accumulators of 16 VGPRs.  K runs in chunks of FC_K = 16 through ONE LDS buffer (A 128 x 17, B 16 x 288 floats, padded so
+// accumulators of 16 VGPRs.  K runs in chunks of FC_K = 16 through two LDS buffers (A 128 x 17, B 16 x 288 floats each, padded so
 // that the operand reads are conflict-free: lane l reads A[l & 31][k + (l >> 5)] and B[k + (l >> 5)][32 n + (l & 31)]); the
-// global loads of chunk i + 1 are issued into registers before chunk i is multiplied and stored to LDS after it; inside a
-// chunk the operands of k-slice j + 1 are read from LDS before the eight MFMAs of slice j issue (209 VGPRs, 27 KB of LDS:
-// two blocks per CU cover each other's barriers).  (Chunks of 32 need 48 staging registers: the compiler then serialises
+// global loads of chunk i + 1 are issued into registers before chunk i is multiplied and stored to the OTHER buffer behind
+// its MFMAs (one barrier per chunk); inside a chunk the operands of k-slice j + 1 are read from LDS before the eight MFMAs
+// of slice j issue (~210 VGPRs, 54 KB of LDS: two blocks per CU).  (Chunks of 32 need 48 staging registers: the compiler then serialises
 // operand reads and MFMAs to stay under 256 VGPRs, or spills.)
 //   ROWS = false: the dense GEMM  H0 [M][256] += Y0 [M][K] x Wd [K][256]  (K = 3840: 240 chunks per tile; C holds the
 //                 per-table term on entry and is added in the epilogue).
@@ -341,8 +341,8 @@ __device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const fl
 template <bool ROWS>
 __global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                 float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
-  __shared__ float sA[FC_M * FC_AS];
-  __shared__ __attribute__((aligned(16))) float sB[FC_K * FC_BS];
+  __shared__ float sA[2][FC_M * FC_AS];
+  __shared__ __attribute__((aligned(16))) float sB[2][FC_K * FC_BS];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * FC_M;
   if (ROWS) {
@@ -361,18 +361,20 @@ __global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int
   for (int n = 0; n < 8; ++n)
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-  fc1_stage(sA, sB, tid, ra, rb);
+  fc1_stage(sA[0], sB[0], tid, ra, rb);
   __syncthreads();
-  const float* pa = sA + (32 * wv + (lane & 31)) * FC_AS + (lane >> 5);
-  const float* pb = sB + (lane >> 5) * FC_BS + (lane & 31);
-  for (int k0 = FC_K; k0 < K; k0 += FC_K) {   // chunk k0 - FC_K is in LDS; chunk k0 travels through the registers meanwhile
+  const int oa = (32 * wv + (lane & 31)) * FC_AS + (lane >> 5), ob = (lane >> 5) * FC_BS + (lane & 31);
+  int cur = 0;
+  for (int k0 = FC_K; k0 < K; k0 += FC_K) {
+    // chunk k0 - FC_K is in LDS buffer `cur`; chunk k0 travels through the registers meanwhile and lands in the other
+    // buffer behind the MFMAs: ONE barrier per chunk (nobody reads the other buffer before it, nobody writes `cur`)
     fc1_load(A, lda, B, m0, M, k0, tid, ra, rb);
-    fc1_chunk(pa, pb, acc);
+    fc1_chunk(sA[cur] + oa, sB[cur] + ob, acc);
+    fc1_stage(sA[cur ^ 1], sB[cur ^ 1], tid, ra, rb);
     __syncthreads();
-    fc1_stage(sA, sB, tid, ra, rb);
-    __syncthreads();
+    cur ^= 1;
   }
-  fc1_chunk(pa, pb, acc);
+  fc1_chunk(sA[cur] + oa, sB[cur] + ob, acc);
 #pragma unroll
   for (int n = 0; n < 8; ++n)
 #pragma unroll

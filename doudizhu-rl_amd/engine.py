@@ -38,7 +38,13 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """the caller's current HIP stream on `device` as a raw pointer (every launch of the library goes there)"""
+    if _raw_stream is not None and device.index is not None:
+        return C.c_void_p(_raw_stream(device.index))      # (~0.3 us; torch.cuda.current_stream() builds a Stream object: ~4 us)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -46,8 +52,8 @@ class BatchedEnv:
     """T tables; table t is global table `table_id_base + t` (keys the RNG)."""
 
     def __init__(self, n_tables, seed=0, device="cuda:0", table_id_base=0, row_capacity=None,
-                 want_ids=True, native_joker_kickers=False, _debug_tables_per_wave=None, _debug_slab_coop=None,
-                 _debug_slab_work_list=None, _debug_auto_teams=None):
+                 want_ids=True, native_joker_kickers=False, host_mirror=False, _debug_tables_per_wave=None,
+                 _debug_slab_coop=None, _debug_slab_work_list=None, _debug_auto_teams=None):
         # native_joker_kickers: the optional rule set with the 24 extra rows the reference's native
         # get_moves is known to emit (server/mcts/get_moves.py:22-34); default off = exactly card.py
         self.native_joker_kickers = bool(native_joker_kickers)
@@ -62,12 +68,22 @@ class BatchedEnv:
         if self.cap > 0x7FFFFFFF:
             raise ValueError("row capacity must be indexable with int32")
         d = self.device
-        self.state = torch.zeros(self.lib.ddz_state_bytes(self.T), dtype=torch.uint8, device=d)
+        # host_mirror (the N = 1 `Env` view): the state rows and the list sizes live in PINNED HOST memory -- the kernels
+        # read and write them over the host link (a few hundred bytes per launch), the host reads them after one stream
+        # synchronisation with no copy at all.  Latency trade for one table; never for a batch.
+        self.host_mirror = bool(host_mirror)
+        if self.host_mirror:
+            self.state = torch.zeros(self.lib.ddz_state_bytes(self.T), dtype=torch.uint8).pin_memory()
+        else:
+            self.state = torch.zeros(self.lib.ddz_state_bytes(self.T), dtype=torch.uint8, device=d)
         self.scratch = torch.zeros(self.lib.ddz_scratch_bytes(self.T), dtype=torch.uint8, device=d)
         self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.rows = torch.zeros((self.cap, ROW), dtype=torch.int8, device=d)
         self.ids = torch.zeros(self.cap, dtype=torch.int32, device=d) if want_ids else None
-        self.counts = torch.zeros(self.T, dtype=torch.int32, device=d)  # slab layout: list sizes
+        if self.host_mirror:
+            self.counts = torch.zeros(self.T, dtype=torch.int32).pin_memory()
+        else:
+            self.counts = torch.zeros(self.T, dtype=torch.int32, device=d)  # slab layout: list sizes
         self.done = torch.zeros(self.T, dtype=torch.uint8, device=d)
         self.reward = torch.zeros(self.T, dtype=torch.int8, device=d)
         self.illegal = torch.zeros(self.T, dtype=torch.uint8, device=d)
@@ -376,6 +392,11 @@ class BatchedEnv:
         self._slab_fresh = True
         return self.counts, self.slab_rows(), self.slab_ids()
 
+    def sync(self):
+        """hipStreamSynchronize on the current stream (ddz_sync): after it a host_mirror environment's state / counts are
+        what the last launch left."""
+        check(self.lib.ddz_sync(self.device.index, _stream(self.device)))
+
     def step_slab(self, sel=None, mode=STEP_CHOICE, auto_reset=True, traj=None):
         """One lock-step iteration in ONE launch: apply `sel` (STEP_CHOICE: int32[T] index into each
         table's slab list; STEP_ROWS: int8[T,16]; STEP_RANDOM: engine RNG) to the lists legal_slab() /
@@ -383,13 +404,15 @@ class BatchedEnv:
         states (game.py:95-106 + envi.py:98-116).  Returns (done, r, illegal) like step()."""
         if not self._slab_fresh:
             self.legal_slab()
+        pinned = sel is not None and sel.device.type == "cpu" and sel.is_pinned()   # (pinned host memory is device-readable)
         if mode in (STEP_CHOICE, STEP_IDS):
-            if sel.dtype != torch.int32 or sel.device != self.device or not sel.is_contiguous():  # (the host side of a
-                sel = sel.to(device=self.device, dtype=torch.int32).contiguous()                  # call costs ~10 us)
+            if sel.dtype != torch.int32 or (sel.device != self.device and not pinned) or not sel.is_contiguous():  # (the host
+                sel = sel.to(device=self.device, dtype=torch.int32).contiguous()               # side of a call costs ~10 us)
             if sel.numel() != self.T:
                 raise ValueError("choice / ids must have one entry per table")
         elif mode == STEP_ROWS:
-            sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
+            if sel.dtype != torch.int8 or (sel.device != self.device and not pinned) or not sel.is_contiguous():
+                sel = sel.to(device=self.device, dtype=torch.int8).contiguous()
             if tuple(sel.shape) != (self.T, ROW):
                 raise ValueError("rows must be [T,16] int8")
         elif mode != STEP_RANDOM:

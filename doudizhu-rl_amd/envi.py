@@ -27,41 +27,50 @@ class Env:
         self.device = torch.device(device) if device is not None else conf.DEVICE
         # `if seed:` in the reference (envi.py:18-21): seed 0 / None -> unseeded
         self._seed = int(seed) if seed else random.getrandbits(63)
-        self._b = BatchedEnv(1, seed=self._seed, device=self.device)
-        self._sel = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._sel_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._row_host = torch.zeros((1, 16), dtype=torch.int8).pin_memory()
-        self._row = torch.zeros((1, 16), dtype=torch.int8, device=self.device)
-        # host mirror of the table, refreshed by ONE synchronisation per ply: the 176-byte state and the size of the new
-        # legal list land in pinned memory behind the launch that produced them (ddz_step_slab applies the move AND
-        # writes the next state's list)
-        self._h_state = torch.zeros(176, dtype=torch.uint8).pin_memory()
-        self._h_count = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # host_mirror: the table's 176 state bytes and its list size live in pinned host memory that the kernels write
+        # directly; one ply = one launch (ddz_step_slab applies the move AND writes the next state's list) + ONE stream
+        # synchronisation, no device -> host copy.  The selection travels the other way through pinned memory too.
+        self._b = BatchedEnv(1, seed=self._seed, device=self.device, host_mirror=True)
+        self._sel = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._row = torch.zeros((1, 16), dtype=torch.int8).pin_memory()
+        self._ids = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._s = self._b.state.numpy().reshape(11, 16)          # live view of the state rows
+        self._n = self._b.counts.numpy()                          # ... and of the size of the legal list
         self._nlegal = 0
         self.debug = debug
-        self._clear()
+        self.old_cards = dict()
 
-    # ---- bookkeeping mirrors (envi.py:22-27); values are read back from the device ----
+    # ---- bookkeeping mirrors (envi.py:22-27): read from the state rows when asked for (fresh copies) ----
+    @property
+    def taken(self):
+        return self._s[F_TAKEN, :15].astype(float)
+
+    @property
+    def left(self):
+        return self._s[F_HAND0:F_HAND0 + 3, 15].astype(int)
+
+    @property
+    def history(self):
+        return collections.defaultdict(lambda: np.zeros((15,)), {r: self._s[F_HIST0 + r, :15].astype(float) for r in range(3)})
+
+    @property
+    def recent_handout(self):
+        return collections.defaultdict(lambda: np.zeros((15,)), {r: self._s[F_RECENT0 + r, :15].astype(int) for r in range(3)})
+
+    @property
+    def _meta(self):
+        return self._s[F_META]
+
+    @property
+    def _hands(self):
+        return self._s[F_HAND0:F_HAND0 + 3, :15]
+
     def _clear(self):
-        self.taken = np.zeros((15,))
-        self.left = np.array([17, 20, 17], dtype=int)
-        self.history = collections.defaultdict(lambda: np.zeros((15,)))
-        self.recent_handout = collections.defaultdict(lambda: np.zeros((15,)))
         self.old_cards = dict()
 
     def _sync(self):
-        self._h_state.copy_(self._b.state, non_blocking=True)
-        self._h_count.copy_(self._b.counts, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()      # the one device -> host round trip of a ply
-        self._nlegal = int(self._h_count[0])
-        s = self._h_state.numpy().reshape(11, 16)
-        self.taken = s[F_TAKEN, :15].astype(float)
-        self.left = s[F_HAND0:F_HAND0 + 3, 15].astype(int)
-        for r in range(3):
-            self.history[r] = s[F_HIST0 + r, :15].astype(float)
-            self.recent_handout[r] = s[F_RECENT0 + r, :15].astype(int)
-        self._meta = s[F_META]
-        self._hands = s[F_HAND0:F_HAND0 + 3, :15].astype(int)
+        self._b.sync()                                            # the one wait of a ply
+        self._nlegal = int(self._n[0])
 
     def reset(self):
         """envi.py:30-36: clears the adapter state; cards are dealt by prepare()."""
@@ -82,8 +91,8 @@ class Env:
 
     def get_last_two_cards(self):
         role = int(self._meta[0])
-        prev = self.arr2cards(self.recent_handout[(role + 2) % 3].astype(int))
-        prevprev = self.arr2cards(self.recent_handout[(role + 1) % 3].astype(int))
+        prev = self.arr2cards(self._s[F_RECENT0 + (role + 2) % 3, :15].astype(int))
+        prevprev = self.arr2cards(self._s[F_RECENT0 + (role + 1) % 3, :15].astype(int))
         return [list(prev), list(prevprev)]
 
     def get_last_outcards(self):
@@ -123,8 +132,7 @@ class Env:
     def _apply(self, idx):
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        self._sel_host[0] = int(idx)
-        self._sel.copy_(self._sel_host, non_blocking=True)
+        self._sel[0] = int(idx)
         r, done = self._step(self._sel, STEP_CHOICE)
         res = (r, done, None)
         if self.debug:
@@ -137,12 +145,7 @@ class Env:
         against the legal list itself (DDZ_STEP_ROWS)."""
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        if torch.is_tensor(onehot_cards) and onehot_cards.is_cuda:
-            # decoded on the device (the row sum of onehot2arr, envi.py:148-157): no device -> host copy of the action
-            self._row[0, :15] = onehot_cards.reshape(15, 4).sum(dim=1).round().to(torch.int8)
-        else:
-            self._row_host[0, :15] = torch.from_numpy(np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8))
-            self._row.copy_(self._row_host, non_blocking=True)
+        self._row[0, :15] = torch.from_numpy(np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8))
         r, done = self._step(self._row, STEP_ROWS)
         if self.debug:
             print('role {} plays {}, left {}'.format(
@@ -155,7 +158,7 @@ class Env:
         (decomposer spec v1)."""
         role = self.get_role_ID() - 1
         self.old_cards[role] = self.get_curr_handcards()
-        ids = self._b.auto_choose(0b111)
+        ids = self._b.auto_choose(0b111, out=self._ids)   # (the id lands in pinned memory; the step reads it from there)
         r, _ = self._step(ids, STEP_IDS)  # (an id the rule agent could not produce -- DDZ_AUTO_INVALID -- raises here)
         cards = self.arr2cards(self.recent_handout[role].astype(int))
         return cards, r, None

@@ -384,6 +384,10 @@ int ddz_status(ddz_env_t* env, int32_t* status_out, void* stream);
  * (bit 3: a cooperating wait hit its hang guard -- the ids of launches since the last call are not to be trusted).
  * Copies 4 bytes D2H on `stream`, clears the word, synchronises.                                                  */
 int ddz_device_status(int device_id, int32_t* status_out, void* stream);
+/* hipStreamSynchronize(stream) on the device: the ONE wait per ply of the N = 1 `Env` view (doudizhu-rl_amd/envi.py), whose
+ * state / list-size buffers live in pinned host memory that the kernels write directly (envi.py:63-116 reads them back
+ * after every native call).  No other entry point of this library waits for the device except ddz_status.           */
+int ddz_sync(int device_id, void* stream);
 
 /* test hook: CardGroup.to_cardgroup (card.py:327-335) of arbitrary count rows int8[n][16] ->
  * out u32[n] = category | value << 8 | len << 16, or 0xFF when the row is no combo.       */
