@@ -42,6 +42,7 @@ struct AutoArgs {
   const int32_t* order;     // k_auto2, STATE form: the tables to decide, heaviest hands first (k_auto_order), or null
   const uint32_t* order_hdr;  // ... and its header (AutoOrder: [0] queue length, [2] positions drawn one by one; device words)
   int teams;                // k_auto2: waves that find the queue empty help the searches still running in their block
+  int team_first;           // k_auto2: the predicted-heaviest decisions (one per block) are searched by their whole block from the start
   double rp[24];            // round_penalty by min_oppo_cards (rule_based_model.py:57), computed on the host
 };
 

@@ -288,11 +288,12 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   __shared__ Auto2Wave s_w[A2_WPB];
   __shared__ A2Team s_team;
   __shared__ uint32_t s_inflight, s_drained;  // waves that may still draw from the queue / that found it empty
+  __shared__ uint32_t s_first_done;           // the block's team-first decision (below) is finished
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   hot_fill<A2_TB>(hot);
   for (int i = threadIdx.x; i < (int)(sizeof(s_team) / 4); i += A2_TB) ((uint32_t*)&s_team)[i] = 0;
-  if (threadIdx.x == 0) { s_inflight = A2_WPB; s_drained = 0; }
+  if (threadIdx.x == 0) { s_inflight = A2_WPB; s_drained = 0; s_first_done = 0; }
   __syncthreads();
   Auto2Wave& W = s_w[wv];
   uint16_t* svl = (uint16_t*)W.ci;               // staging views of ci: value | len << 8 ...
@@ -316,7 +317,17 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   // ... whose first NH positions are (about) the hands of 13 + cards: one per draw (a share of eight of those could be a
   // millisecond)
   const int64_t NH = a.order ? (int64_t)rfl(a.order_hdr[2]) : 0;  // AutoOrder::nsingle
+  // Team first (round 4): the KT predicted-heaviest decisions -- the head of the ordered queue, one per block -- are searched
+  // by the WHOLE block from their first trip: wave 0 owns position blockIdx.x, opens its team as soon as a lane has a
+  // level to give, and the block's other waves start as its helpers instead of drawing tickets (a decision of 10^4 nodes
+  // alone on one wave lasted as long as everything else of the launch per wave: it was the launch, wherever it sat in the
+  // queue).  The ticket then hands out the positions from KT on.
+  const int64_t KT = (a.order && a.teams && a.team_first) ? (NH < (int64_t)gridDim.x ? NH : (int64_t)gridDim.x) : 0;
+  bool first_owner = wv == 0 && (int64_t)blockIdx.x < KT;    // this wave owns the block's team-first decision
+  bool first_helper = wv != 0 && (int64_t)blockIdx.x < KT;   // ... helps it until it is finished
   int64_t tnext = 0, tend = 0;  // queue positions in hand: [tnext, tend)
+  if (first_owner) { tnext = (int64_t)blockIdx.x; tend = tnext + 1; }
+  bool first_started = false;   // the owner is inside its team-first decision (whichever way it leaves it, the loop's top sees it)
   int64_t seen = 0;             // the queue's head as of this wave's last draw
   // Teams: one decision in a few hundred walks 10^4 nodes, and whenever a launch holds one, that search -- alone on its
   // wave, every other wave done -- WAS the rest of the launch (a third of the average launch).  A wave that finds the
@@ -331,14 +342,18 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
   uint32_t polls = 0;           // hang guard of the waiting loops (status bit 3; never reached in a working launch)
   constexpr uint32_t A2_POLL_LIMIT = 1u << 24;
   for (;;) {
+    if (first_started) {        // the block's team-first decision is finished: its helpers may go to the queue now
+      first_started = false; first_owner = false;
+      if (lane == 0) __hip_atomic_store(&s_first_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // (taking the next ticket early, to fetch its state rows while this table is decided, was slower: a wave inside a
     // 10^6-cycle decision then holds its next table hostage)
-    if (!drained && tnext >= tend) {
+    if (!drained && !first_helper && tnext >= tend) {
       int64_t sz = (NQ - seen) / ((a.order ? 4 : 8) * nwaves);
       sz = (sz < 1 || seen < NH) ? 1 : sz > 8 ? 8 : sz;
       uint32_t tk = 0;
       if (lane == 0) tk = atomicAdd(a.ticket, (uint32_t)sz);
-      seen = (int64_t)rfl(tk);
+      seen = KT + (int64_t)rfl(tk);
       if (seen >= NQ) {
         if (!a.teams) break;
         drained = true;
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       }
     }
     int own = wv, my_slot = 0;  // whose search this wave works on, and as which member
-    if (drained) {              // join a team of the block, or leave when none can open any more
+    if (drained || first_helper) {  // join a team of the block, or leave when none can open any more
       own = -1;
       // (peeks first: a wave that cannot join must not keep the lock busy -- seven such waves starved the owner)
       if (a2_peek(&s_team.open) && (a2_peek(&s_team.active) != 0 || a2_peek(&s_team.box_n) != 0) &&
@@ -364,6 +379,12 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
         a2_unlock(&TK.lock, lane);
       }
       if (own < 0) {
+        if (first_helper) {     // no team to join (yet, or any more): on to the queue once the owner is through
+          if (a2_peek(&s_first_done) != 0) { first_helper = false; polls = 0; continue; }
+          if (++polls > A2_POLL_LIMIT) { if (lane == 0 && a.status) atomicOr(a.status, 8); first_helper = false; continue; }
+          __builtin_amdgcn_s_sleep(4);
+          continue;
+        }
         if (a2_peek(&s_inflight) == 0) break;
         if (++polls > A2_POLL_LIMIT) { if (lane == 0 && a.status) atomicOr(a.status, 8); break; }
         __builtin_amdgcn_s_sleep(16);
@@ -373,6 +394,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
     const bool helper = own != wv;
     const int64_t t = helper ? 0 : a.order ? (int64_t)rfl((uint32_t)a.order[tnext]) : tnext;
     if (!helper) ++tnext;
+    if (first_owner) first_started = true;
     // what the search below works with: the owner's own preparation (1, 1b, 2), or the context the team's owner published
     A2Ctx q;
     uint64_t bsw0 = 0, bsw1 = 0, bsw2 = 0;  // bucket starts of the sorted candidates (seven 9-bit entries per word)
@@ -937,7 +959,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           else if (thr > tt && lane == 0) a2_thr_store(TM, thr);
         }
       }
-      if (a.teams && (in_team ? (trip & 1) == 0 : (trip & 3) == 0 && trip >= 8)) {
+      if (a.teams && (in_team ? (trip & 1) == 0 : (trip & 3) == 0 && (trip >= 8 || first_owner))) {
         const bool can_give_t = act && more != 0 && (more & (0u - more)) < ((pendopen & (0u - pendopen)) | 0x80000000u) &&
                                 n0 + __builtin_ctz(more | 0x80000000u) < A2_KEYLEVELS;
         const uint64_t donors_t = __ballot(can_give_t);
@@ -950,7 +972,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           A2DBG(8, n_act); A2DBG(9, n_none); A2DBG(10, n_pend); A2DBG(11, n_key); A2DBG(12, __popcll(donors_t));
         }
 #endif
-        if (!in_team && donors_t && a2_peek(&s_drained) != 0 && !a2_peek(&TM.open)) {
+        if (!in_team && donors_t && (a2_peek(&s_drained) != 0 || first_owner) && !a2_peek(&TM.open)) {
           // the owner opens the team: waves of the block have run out of queue, this search has lasted a while and has
           // subtrees to give (and no other search of the block is being shared)
           a2_lock(&TM.lock, lane, a.status);
@@ -1242,6 +1264,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
       a.ids[t] = bm < 0 ? 0 : bm;  // rule_based_model.py:87-89
       if (a.stats) { a.stats[2 * t] = combs; a.stats[2 * t + 1] = nodes; }
     }
+
 #ifdef DDZ_STAMP
     if (g_stamps && lane == 0 && !helper) {
       g_stamps[16 * t + 0] = tq[1] - tq[0]; g_stamps[16 * t + 1] = tq[2] - tq[1]; g_stamps[16 * t + 2] = tq[3] - tq[2];

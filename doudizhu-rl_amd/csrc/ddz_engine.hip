@@ -3077,7 +3077,7 @@ int ddz_auto_choose_state(ddz_env_t* e, int auto_roles, int32_t* ids, int64_t* s
   if (!g.ok) return DDZ_ENODEV;
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
-  a.status = e->sc.status; a.teams = e->auto_teams;
+  a.status = e->sc.status; a.teams = e->auto_teams != 0; a.team_first = e->auto_teams == 1;
   fill_round_penalty(a);
   return launch_auto_ordered(e, a, (hipStream_t)stream);
 }
@@ -3093,7 +3093,7 @@ int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_
   if (!g.ok) return DDZ_ENODEV;
   AutoArgs a{};
   a.state = e->state; a.T = e->T; a.tpw = 1; a.auto_roles = auto_roles; a.ids = ids; a.stats = stats;
-  a.status = e->sc.status; a.teams = e->auto_teams;
+  a.status = e->sc.status; a.teams = e->auto_teams != 0; a.team_first = e->auto_teams == 1;
   fill_round_penalty(a);
   if (kernel == AUTO_K_LANES) return launch_auto_ordered(e, a, (hipStream_t)stream);
   return launch_auto<true>(e->device, a, (hipStream_t)stream, kernel == AUTO_K_SEQUENTIAL ? AUTO_K_SEQUENTIAL : AUTO_K_LANES);
@@ -3118,7 +3118,7 @@ int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int
 
 int ddz_debug_set_auto_teams(ddz_env_t* e, int on) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (on < 0 || on > 1) return DDZ_EINVAL;
+  if (on < 0 || on > 2) return DDZ_EINVAL;   // 0 off, 1 teams + team-first for the heaviest decisions (default), 2 teams at the queue's end only
   e->auto_teams = on;
   return DDZ_OK;
 }

@@ -103,7 +103,7 @@ class BatchedEnv:
                                                   -1 if _debug_slab_work_list is None else int(bool(_debug_slab_work_list))))
         if _debug_auto_teams is not None:
             # test hook: auto_choose's wavefronts without tables help their workgroup's running searches (default) or not
-            check(self.lib.ddz_debug_set_auto_teams(h, int(bool(_debug_auto_teams))))
+            check(self.lib.ddz_debug_set_auto_teams(h, int(_debug_auto_teams)))   # 0 off, 1 default, 2 teams without team-first
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: tables on one MI355X with Q-net inference in the loop (SURVEY 8d "Config 3").
 
-Per lock-step iteration (doudizhu-rl_amd/dqn_glue.py PolicyLoop, nothing on the host in between):
-  face (EnvCooperationSimplify planes) -> FactorisedQ.tables: the first layer per (table, rank, count) as dense GEMMs
-  -> ddz_q_slab: Q of EVERY legal action of every table over the slab lists -> ddz_policy_step_slab: greedy arg-max,
-  apply, next lists, next face in one launch.
+Per lock-step iteration (doudizhu-rl_amd/dqn_glue.py PolicyLoop, needed-rows form, nothing on the host in between):
+  face (EnvCooperationSimplify planes) -> ddz_q_need (the (rank, count) rows the legal moves use) -> ddz_q_features_needed
+  (first layer) -> ddz_q_fc1_dense + ddz_q_fc1_rows (fc1 on the fp32 MFMA kernel k_fc1) -> ddz_q_slab_needed: Q of EVERY
+  legal action of every table over the slab lists -> ddz_policy_step_slab: greedy arg-max, apply, next lists, next face.
 The network has the architecture and parameter names of the reference's NetCooperationSimplify (net.py:137-150, forward
 net.py:81-102), randomly initialised (no trained weights ship with the reference), eval mode.
 
@@ -25,6 +25,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--tables", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mode", default="needed", choices=("needed", "packed", "full"))
+    ap.add_argument("--gemm", default="mfma", choices=("mfma", "torch"))
+    ap.add_argument("--stages", action="store_true", help="also print the per-stage device times (HIP events)")
     a = ap.parse_args(argv)
     pkg = importlib.import_module("doudizhu-rl_amd")
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
@@ -34,7 +37,7 @@ def main(argv=None):
     T = a.tables
     env = pkg.BatchedEnv(T, seed=0, device=dev)
     env.reset()
-    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0)
+    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, mode=a.mode, gemm=a.gemm)
     loop.run(2)
     torch.cuda.synchronize()
     s0 = env.stats()
@@ -48,6 +51,10 @@ def main(argv=None):
            "legal_rows_per_table": rows / a.iters / T, "q_evals_per_s": rows / dt, "episodes": s1["episodes"],
            "status": env.status()}
     print(out)
+    if a.stages and a.mode == "needed":
+        for k, v in loop.profile(10).items():
+            rate = f"{v['flop'] / v['us'] / 1e6:8.1f} TFLOP/s" if v.get("flop") else f"{v['bytes'] / v['us'] / 1e3:8.1f} GB/s"
+            print(f"  {k:12s} {v['us']:9.1f} us  {rate}  {v['kernel']}")
     return out
 
 

@@ -370,7 +370,9 @@ int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int3
  * variables.                                                                                                     */
 int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_work_list);
 /* test hook: ddz_auto_choose_state's wavefronts that run out of tables help the searches still running in their
- * workgroup (1, the default) or leave (0).  Same ids and stats either way (tests compare them).                   */
+ * workgroup, and the predicted-heaviest decisions (one per workgroup) are searched by their whole workgroup from the start
+ * (1, the default); 2 = the first only (round 3's behaviour); 0 = neither.  Same ids and stats in every mode (tests
+ * compare them).                                                                                                  */
 int ddz_debug_set_auto_teams(ddz_env_t* env, int on);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,

@@ -50,8 +50,10 @@ for pass in "$@"; do
       head -4 $O/stats/p_kernel_stats.csv; cat $O/config4_*.txt ;;
     dqn)
       stats $O/stats python3 examples/config3_dqn_inference.py --iters 10
-      python3 examples/config3_dqn_inference.py --iters 20 > $O/config3.txt 2>&1
-      head -12 $O/stats/p_kernel_stats.csv; tail -1 $O/config3.txt ;;
+      pmc $O/p_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" python3 examples/config3_dqn_inference.py --iters 8
+      for c in FETCH_SIZE WRITE_SIZE; do pmc $O/pmc_$c $c python3 examples/config3_dqn_inference.py --iters 6; done
+      python3 examples/config3_dqn_inference.py --iters 20 --stages > $O/config3.txt 2>&1
+      head -14 $O/stats/p_kernel_stats.csv; tail -3 $O/config3.txt ;;
     secondary)
       stats $O/observe_stats python3 tools/observe_probe.py 65536,524288
       for c in FETCH_SIZE WRITE_SIZE; do pmc $O/observe_pmc_$c $c python3 tools/observe_probe.py 524288; done
