@@ -2650,7 +2650,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
   e->slab_lpt = e->tpw >= 2;
-  e->auto_teams = 1;
+  e->auto_teams = 2;   // teams at the queue's end (1 = also team-first for the predicted-heaviest: measured, no gain -- DESIGN.md 9)
   *out = e;
   return DDZ_OK;
 }

@@ -22,7 +22,7 @@
 constexpr int QN_TPB = 64;           // tables per block of the need kernels (four lanes per table)
 constexpr int QN_SEG_WORDS = 40;     // seg[0..15] first row of rank r's segment (multiples of FC_M), [15] = rows in use,
                                      // seg[16..31] first TILE of rank r, [31] = tiles in use, seg[32] = rows needed, [33] = overflow
-constexpr int FC_M = 128, FC_K = 16, FC_N = 256;   // k_fc1's tile: 128 rows x all 256 fc1 outputs, K in chunks of 16
+constexpr int FC_M = 256, FC_K = 16, FC_N = 256;   // k_fc1's tile: 256 rows x all 256 fc1 outputs, K in chunks of 16
 
 __device__ __forceinline__ uint64_t q_need_of_row(uint64_t nib) {
   // nibble c in 1..4 of rank r < 13 -> bit c - 1 of the same nibble (SWAR over the 13 nibbles); jokers -> bits 52, 53
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restric
   int4* dst = (int4*)(row_index + t * QP_COLS + 16 * q);
 #pragma unroll
   for (int i = 0; i < 4; ++i) dst[i] = make_int4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
-  if (dropped) atomicOr(status, 2);   // row capacity overflow (cannot happen with capacity >= 20 T + 15 * 128)
+  if (dropped) atomicOr(status, 2);   // row capacity overflow (cannot happen with capacity >= 20 T + 15 * FC_M)
 }
 
 // ---- 2. first layer for the needed rows ----------------------------------------------------------------------------------
@@ -267,13 +267,14 @@ __global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__
 // ---- 3. fc1 on the matrix cores, exact f32 ---------------------------------------------------------------------------------
 // C[m][0..255] (+)= sum_k A[m][k] * B[k][0..255] with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered
 // fmaf chain; 64 cycles per instruction and SIMD = the fp32 vector peak, 157.3 TFLOP/s).  Block = 256 threads = 4 wavefronts,
-// tile = 128 rows x all 256 outputs (A is read from HBM once), wave w owns rows 32 w .. 32 w + 31 x 8 column tiles = 8
-// accumulators of 16 VGPRs.  K runs in chunks of FC_K = 16 through two LDS buffers (A 128 x 17, B 16 x 288 floats each, padded so
-// that the operand reads are conflict-free: lane l reads A[l & 31][k + (l >> 5)] and B[k + (l >> 5)][32 n + (l & 31)]); the
-// global loads of chunk i + 1 are issued into registers before chunk i is multiplied and stored to the OTHER buffer behind
-// its MFMAs (one barrier per chunk); inside a chunk the operands of k-slice j + 1 are read from LDS before the eight MFMAs
-// of slice j issue (~210 VGPRs, 54 KB of LDS: two blocks per CU).  (Chunks of 32 need 48 staging registers: the compiler then serialises
-// operand reads and MFMAs to stay under 256 VGPRs, or spills.)
+// ONE block per CU (one wave per SIMD, the whole register file: 256 accumulator registers per lane), tile = 256 rows x all 256
+// outputs (A is read from HBM once), wave (wm, wn) owns rows 128 wm .. + 127 x columns 128 wn .. + 127 = 4 x 4 accumulators of
+// 16 VGPRs: per k-slice eight operand registers feed sixteen MFMAs.  K runs in chunks of FC_K = 16 through two LDS buffers (A
+// 256 x 17, B 16 x 288 floats each, padded so that the operand reads are conflict-free: lane l reads A[l & 31][k + (l >> 5)]
+// and B[k + (l >> 5)][32 n + (l & 31)]); the global loads of chunk i + 1 are issued into registers before chunk i is
+// multiplied and stored to the OTHER buffer behind its MFMAs: one barrier per 128 MFMAs of a wave.
+// (First version: 128-row tiles, wave tile 32 x 256, two blocks per CU: 125 TFLOP/s on the dense GEMM, its matrix pipes busy
+// 79 % of the cycles at 2.22 GHz -- nine operand reads per eight MFMAs and a barrier per 64; profiles/r04_dqn_pmc.json.)
 //   ROWS = false: the dense GEMM  H0 [M][256] += Y0 [M][K] x Wd [K][256]  (K = 3840: 240 chunks per tile; C holds the
 //                 per-table term on entry and is added in the epilogue).
 //   ROWS = true : D [row][256] = dY [row][256] x W2[rank of the row][256][256]: tile b belongs to the rank r with
@@ -282,7 +283,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;   // (native vectors: HIP's float4 struct arrays end up in scratch here)
 constexpr int FC_AS = FC_K + 1;      // LDS row stride of A (floats)
 constexpr int FC_BS = FC_N + 32;     // ... of B
-constexpr int FC_NA = FC_K / 8, FC_NB = FC_K / 4;   // float4 per thread and chunk: A 128 x FC_K floats, B FC_K x 256
+constexpr int FC_NA = FC_M * FC_K / 4 / 256, FC_NB = FC_K * FC_N / 4 / 256;   // float4 per thread and chunk: A FC_M x FC_K floats, B FC_K x 256
 __device__ __forceinline__ void fc1_load(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t m0, int64_t M,
                                          int k0, int tid, f32x4 (&ra)[FC_NA], f32x4 (&rb)[FC_NB]) {
   // global -> registers: A row f / (FC_K / 4), k 4 (f % (FC_K / 4)); B row f / 64, columns 4 (f % 64)
@@ -312,38 +313,41 @@ __device__ __forceinline__ void fc1_stage(float* __restrict__ sA, float* __restr
     *(f32x4*)(sB + row * FC_BS + 4 * c4) = rb[i];
   }
 }
-__device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const float* __restrict__ pb, f32x16 (&acc)[8]) {
-  // the operands of k-slice kk + 2 are read from LDS before the eight MFMAs of slice kk are issued (explicit double buffer:
-  // an LDS read then has 8 x 64 cycles of matrix work to land in)
-  float a0 = pa[0], b0[8], a1 = 0.f, b1[8];
+// one chunk of FC_K: wave (wm, wn) multiplies its 128 rows x 128 columns = 4 x 4 tiles of 32 x 32 -- per k-slice of 2 four A
+// and four B operand registers feed sixteen MFMAs; the operands of k-slice kk + 2 are read from LDS before the MFMAs of slice
+// kk are issued (explicit double buffer: an LDS read has 16 x 64 cycles of matrix work to land in)
+__device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const float* __restrict__ pb, f32x16 (&acc)[4][4]) {
+  float a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) { b0[n] = pb[32 * n]; b1[n] = 0.f; }
+  for (int i = 0; i < 4; ++i) { a0[i] = pa[32 * i * FC_AS]; b0[i] = pb[32 * i]; a1[i] = 0.f; b1[i] = 0.f; }
 #pragma unroll
   for (int kk = 0; kk < FC_K; kk += 4) {
-    a1 = pa[kk + 2];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) b1[n] = pb[(kk + 2) * FC_BS + 32 * n];
+    for (int i = 0; i < 4; ++i) { a1[i] = pa[32 * i * FC_AS + kk + 2]; b1[i] = pb[(kk + 2) * FC_BS + 32 * i]; }
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads next to their MFMAs to save registers)
 #pragma unroll
-    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kk + 4 < FC_K) {
-      a0 = pa[kk + 4];
 #pragma unroll
-      for (int n = 0; n < 8; ++n) b0[n] = pb[(kk + 4) * FC_BS + 32 * n];
+      for (int i = 0; i < 4; ++i) { a0[i] = pa[32 * i * FC_AS + kk + 4]; b0[i] = pb[(kk + 4) * FC_BS + 32 * i]; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <bool ROWS>
-__global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+__global__ __launch_bounds__(256, 1) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                 float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
   __shared__ float sA[2][FC_M * FC_AS];
   __shared__ __attribute__((aligned(16))) float sB[2][FC_K * FC_BS];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int64_t m0 = (int64_t)blockIdx.x * FC_M;
   if (ROWS) {
     if ((int)blockIdx.x >= seg[31]) return;
@@ -355,15 +359,17 @@ __global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int
   }
   f32x4 ra[FC_NA], rb[FC_NB];
   fc1_load(A, lda, B, m0, M, 0, tid, ra, rb);
-  f32x16 acc[8];
+  f32x16 acc[4][4];
   const int crow = 4 * (lane >> 5), ccol = lane & 31;   // C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int n = 0; n < 8; ++n)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   fc1_stage(sA[0], sB[0], tid, ra, rb);
   __syncthreads();
-  const int oa = (32 * wv + (lane & 31)) * FC_AS + (lane >> 5), ob = (lane >> 5) * FC_BS + (lane & 31);
+  const int oa = (128 * wm + (lane & 31)) * FC_AS + (lane >> 5), ob = (lane >> 5) * FC_BS + 128 * wn + (lane & 31);
   int cur = 0;
   for (int k0 = FC_K; k0 < K; k0 += FC_K) {
     // chunk k0 - FC_K is in LDS buffer `cur`; chunk k0 travels through the registers meanwhile and lands in the other
@@ -376,12 +382,15 @@ __global__ __launch_bounds__(256, 2) void k_fc1(const float* __restrict__ A, int
   }
   fc1_chunk(sA[cur] + oa, sB[cur] + ob, acc);
 #pragma unroll
-  for (int n = 0; n < 8; ++n)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int64_t row = m0 + 32 * wv + (g & 3) + 8 * (g >> 2) + crow;
-      if (row < M) C[row * FC_N + 32 * n + ccol] = ROWS ? acc[n][g] : acc[n][g] + C[row * FC_N + 32 * n + ccol];
-    }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int64_t row = m0 + 128 * wm + 32 * i + (g & 3) + 8 * (g >> 2) + crow;
+        const int col = 128 * wn + 32 * j + ccol;
+        if (row < M) C[row * FC_N + col] = ROWS ? acc[i][j][g] : acc[i][j][g] + C[row * FC_N + col];
+      }
 }
 
 // ---- 4. the per-row stage over the needed rows -------------------------------------------------------------------------------

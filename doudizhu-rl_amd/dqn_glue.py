@@ -132,6 +132,7 @@ import torch.nn as nn  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 _CONV_CH = 256
+FC_TILE = 256    # rows per tile of the engine's fc1 kernel (csrc/ddz_qnet.h FC_M): rank segments start at multiples of it
 
 
 class QNet(nn.Module):
@@ -376,7 +377,7 @@ class FactorisedQ:
             raise ValueError(f"face must be a device tensor [T,{P},15,4] of the environment's tables")
         key = ("needed", face.device, T)
         if key not in self._ws:
-            cap = (20 * T + 15 * 128 + 127) // 128 * 128               # a move takes at most what the actor holds: <= 20 cards
+            cap = (20 * T + 15 * FC_TILE + FC_TILE - 1) // FC_TILE * FC_TILE   # a move takes at most what the actor holds: <= 20 cards
             dev = face.device
             self._ws[key] = {"cap": cap, "y0": torch.zeros((T, 15 * H), dtype=torch.float32, device=dev),
                              "dy": torch.zeros((cap, H), dtype=torch.float32, device=dev),
@@ -416,7 +417,7 @@ class FactorisedQ:
     @torch.no_grad()
     def needed_torch(self, face, rows, offsets):
         """The same in plain torch from CSR lists (any device): the statement the engine's needed-rows kernels are tested
-        against -- same row layout (rank segments from multiples of 128, inside a segment table-major then count), so
+        against -- same row layout (rank segments from multiples of FC_TILE, inside a segment table-major then count), so
         row_index and seg compare exactly."""
         if self._ver != self._versions():
             self.refresh()
@@ -430,9 +431,9 @@ class FactorisedQ:
         starts = []
         for r in range(15):
             starts.append(row)
-            seg[r], seg[16 + r] = row, row // 128
-            row += (int(n_r[r]) + 127) // 128 * 128
-        seg[15], seg[31], seg[32] = row, row // 128, int(n_r.sum())
+            seg[r], seg[16 + r] = row, row // FC_TILE
+            row += (int(n_r[r]) + FC_TILE - 1) // FC_TILE * FC_TILE
+        seg[15], seg[31], seg[32] = row, row // FC_TILE, int(n_r.sum())
         excl = per_rank.long().cumsum(1) - per_rank.long()
         idx = torch.where(per_rank, excl + torch.tensor(starts, device=dev)[:, None], -1).view(15, T, 4).permute(1, 0, 2)
         row_index = torch.full((T, 64), -1, dtype=torch.int32, device=dev)
@@ -440,8 +441,8 @@ class FactorisedQ:
         row_index[:, 52], row_index[:, 53] = idx[:, 13, 0].to(torch.int32), idx[:, 14, 0].to(torch.int32)
         Y = self._first_layer_torch(face)                               # [15,5,T,H]
         y0 = Y[:, 0].permute(1, 0, 2).reshape(T, 15 * H).contiguous()
-        dy = torch.zeros((max(row, 128), H), dtype=torch.float32, device=dev)
-        d = torch.zeros((max(row, 128), H1), dtype=torch.float32, device=dev)
+        dy = torch.zeros((max(row, FC_TILE), H), dtype=torch.float32, device=dev)
+        d = torch.zeros((max(row, FC_TILE), H1), dtype=torch.float32, device=dev)
         for r in range(15):
             for c in range(1, 5 if r < 13 else 2):
                 dst = idx[:, r, c - 1]
@@ -663,7 +664,7 @@ class PolicyLoop:
                           "flop": 2.0 * T * 15 * H * H, "note": "H0 += y0 [T, 3840] x Wd [3840, 256]"},
             "fc1_rows": {"us": us["fc1_rows"], "kernel": "k_fc1<true>", "flop": 2.0 * rn * H * H,
                          "note": f"D = dY x fc1[rank]: {rn:.0f} needed rows per iteration ({rn / T:.2f} per table), {rp:.0f} computed "
-                                 "with the padding of the fifteen 128-row-aligned segments; FLOP of the needed rows"},
+                                 "with the padding of the fifteen tile-aligned (256-row) segments; FLOP of the needed rows"},
             "row_stage": {"us": us["row_stage"], "kernel": "k_q_slab_needed", "bytes": T * H * 4 + rn * H * 4 + mv * 20,
                           "note": "H0 + the needed D rows + the list rows read, q written"},
             "env_step": {"us": us["env_step"], "kernel": "k_slab<4,true>", "bytes": T * (2 * 176 + P * 240 + 8) + mv * 24,

@@ -39,6 +39,17 @@ class Env:
         self._nlegal = 0
         self.debug = debug
         self.old_cards = dict()
+        # lean call paths of the three per-ply calls (face / valid_actions / step): the library functions bound once, the
+        # persistent buffers' pointers converted once (the generic BatchedEnv wrappers spend ~10 us per call on checks)
+        import ctypes as C
+        from .engine import FACE_PLANES, _raw_stream
+        b = self._b
+        self._C, self._L, self._h, self._di = C, b.lib, b._h, b.device.index
+        self._P = FACE_PLANES[self.FACE_VARIANT]
+        self._rows_ptr = b.rows.data_ptr()
+        self._pp = b._pp
+        self._sel_p, self._row_p, self._ids_p = (C.c_void_p(x.data_ptr()) for x in (self._sel, self._row, self._ids))
+        self._raw = _raw_stream if _raw_stream is not None else (lambda i: torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- bookkeeping mirrors (envi.py:22-27): read from the state rows when asked for (fresh copies) ----
     @property
@@ -69,7 +80,10 @@ class Env:
         self.old_cards = dict()
 
     def _sync(self):
-        self._b.sync()                                            # the one wait of a ply
+        rc = self._L.ddz_sync(self._di, self._C.c_void_p(self._raw(self._di)))   # the one wait of a ply
+        if rc:
+            from ._lib import check
+            check(rc)
         self._nlegal = int(self._n[0])
 
     def reset(self):
@@ -122,7 +136,16 @@ class Env:
         if self._meta[1]:  # a finished table stays as it is (no auto-reset in this view)
             return 0, True
         before = self._ply()
-        self._b.step_slab(sel, mode, auto_reset=False)
+        b, pp = self._b, self._pp
+        if not b._slab_fresh:
+            b.legal_slab()
+        sel_p = self._sel_p if sel is self._sel else self._row_p if sel is self._row else self._ids_p
+        rc = self._L.ddz_step_slab(self._h, mode, sel_p, pp["counts"], pp["rows"], pp["ids"], b.slab_stride, 0, pp["done"],
+                                   pp["reward"], pp["illegal"], None, self._C.c_void_p(self._raw(self._di)))
+        if rc:
+            from ._lib import check
+            check(rc)
+        b._legal_fresh, b._slab_fresh, b._csr_fresh = False, True, False    # (as BatchedEnv.step_slab)
         self._sync()
         if self._ply() == before:
             raise ValueError("illegal action for the current state")
@@ -175,13 +198,25 @@ class Env:
     # ---- observations ----
     @property
     def face(self):
-        return self._b.observe(self.FACE_VARIANT)[0]
+        out = torch.empty((self._P, 15, 4), dtype=torch.float32, device=self.device)
+        rc = self._L.ddz_observe(self._h, self.FACE_VARIANT, self._C.c_void_p(out.data_ptr()), self._C.c_void_p(self._raw(self._di)))
+        if rc:
+            from ._lib import check
+            check(rc)
+        return out
 
     def valid_actions(self, tensor=True):
         """envi.py:98-116: f32 [A,15,4] on the device, or a list of A int[15] arrays."""
         rows, n = self._legal()
         if tensor:
-            return rows_to_onehot(rows[:n])
+            out = torch.empty((n, 15, 4), dtype=torch.float32, device=self.device)
+            if n:
+                rc = self._L.ddz_rows_to_onehot(self._di, self._C.c_void_p(self._rows_ptr), n, self._C.c_void_p(out.data_ptr()),
+                                                self._C.c_void_p(self._raw(self._di)))
+                if rc:
+                    from ._lib import check
+                    check(rc)
+            return out
         return [a for a in rows[:n, :15].cpu().numpy().astype(int)]
 
     # ---- codecs (envi.py:118-161), host-side like the reference's ----

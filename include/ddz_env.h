@@ -297,9 +297,9 @@ int ddz_q_slab_packed(ddz_env_t* env, const float* u, const int32_t* row_index, 
  *   D[row] = fc1_r^T (Y[t][r][c] - Y[t][r][0]), c >= 1             only for the (r, c) some LEGAL MOVE of table t takes
  * ddz_q_need: finds those (r, c) from the slab lists (counts / rows as ddz_step_slab left them) and lays their rows out in
  *   fifteen rank segments: row_index int32 [T][64] (columns as above; -1 = not needed) and seg int32 [40] (DEVICE memory:
- *   [r] first row of rank r's segment -- a multiple of 128 --, [15] rows in use, [16 + r] first 128-row tile of rank r, [31]
+ *   [r] first row of rank r's segment -- a multiple of 256 --, [15] rows in use, [16 + r] first 256-row tile of rank r, [31]
  *   tiles in use, [32] rows needed, [33] 1 if row_capacity was too small -- then status bit 1 is raised and the rows that did
- *   not fit are -1).  row_capacity: rows of dy / d, a multiple of 128, >= 15 * 128; 20 T + 15 * 128 always suffices (a move
+ *   not fit are -1).  row_capacity: rows of dy / d, a multiple of 256, >= 15 * 256; 20 T + 15 * 256 always suffices (a move
  *   takes at most what the actor holds: <= 20 cards).  scratch: ddz_q_need_scratch_bytes(T) bytes, 256-byte aligned.
  * ddz_q_features_needed: the first layer (as ddz_q_features) into y0 f32 [T][15 * 256] (count 0 of every rank: the dense
  *   GEMM's left operand) and dy f32 [row_capacity][256] (Y[t][r][c] - Y[t][r][0] at the row of every needed (t, r, c)).
@@ -369,10 +369,10 @@ int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int3
  * 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads no environment
  * variables.                                                                                                     */
 int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_work_list);
-/* test hook: ddz_auto_choose_state's wavefronts that run out of tables help the searches still running in their
- * workgroup, and the predicted-heaviest decisions (one per workgroup) are searched by their whole workgroup from the start
- * (1, the default); 2 = the first only (round 3's behaviour); 0 = neither.  Same ids and stats in every mode (tests
- * compare them).                                                                                                  */
+/* test hook: 2 (the default) = ddz_auto_choose_state's wavefronts that run out of tables help the searches still running in
+ * their workgroup; 1 = additionally the predicted-heaviest decisions (one per workgroup) are searched by their whole
+ * workgroup from the start ("team first": built and measured in round 4, no gain, off by default); 0 = neither.  Same ids
+ * and stats in every mode (tests compare them).                                                                    */
 int ddz_debug_set_auto_teams(ddz_env_t* env, int on);
 
 /* device status word: bit0 enumerator/count mismatch, bit1 row capacity overflow,
