@@ -680,13 +680,14 @@ def main():
     steps_per_launch = steps_timed / n_launch
     b_launch = b_step * steps_per_launch
     dominant = "k_rollout"
+    pmc_key = "k_rollout_65536" if T >= 32768 and "k_rollout_65536" in (_profile("pmc_traffic.json") or {}) else "k_rollout"
     traffic, traffic_source = None, None
-    prof = (_profile("pmc_traffic.json") or {}).get(dominant, {})
+    prof = (_profile("pmc_traffic.json") or {}).get(pmc_key, {})
     if prof.get("hbm_bytes_per_env_step") is not None:
         traffic = prof["hbm_bytes_per_env_step"] * steps_per_launch
         traffic_source = ("REPLAYED, not measured in this run: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                           "separate passes, FETCH doubled per the gfx950 note; " + str(prof.get("workload", "")) + ") x this run's env steps per launch")
-    issue = issue_block("k_rollout", steps_per_launch, dur_launch)
+    issue = issue_block(pmc_key if pmc_key in (_profile("pmc_kernels.json") or {}) else "k_rollout", steps_per_launch, dur_launch)
     ach = b_launch / dur_launch / 1e9
 
     # ---- the same loop with packed CSR lists (one launch per iteration): a number, not the headline

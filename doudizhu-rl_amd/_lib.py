@@ -64,6 +64,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddz_q_slab_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ddz_q_fc1_tile_rows": (C.c_int, []),
     "ddz_q_need_scratch_bytes": (C.c_int64, [C.c_int64]),
     "ddz_q_need": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                              C.c_void_p]),

@@ -3275,6 +3275,8 @@ int ddz_q_slab_packed(ddz_env_t* e, const float* u, const int32_t* row_index, co
 }
 
 // ---- the "needed rows" form of the ragged Q forward (ddz_qnet.h) ----
+int ddz_q_fc1_tile_rows(void) { return FC_M; }
+
 int64_t ddz_q_need_scratch_bytes(int64_t n_tables) {
   if (n_tables <= 0) return 0;
   const int64_t nblk = (n_tables + QN_TPB - 1) / QN_TPB;
@@ -3327,7 +3329,7 @@ int ddz_q_fc1_dense(int device, const float* a, int64_t n_rows, int64_t k, const
   if (n_rows > ((int64_t)1 << 31) - FC_M) return DDZ_ECAP;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
-  hipLaunchKernelGGL(k_fc1<false>, dim3((unsigned)((n_rows + FC_M - 1) / FC_M)), dim3(256), 0, (hipStream_t)stream, a, k, w, c,
+  hipLaunchKernelGGL(k_fc1<false>, dim3((unsigned)((n_rows + FC_M - 1) / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, a, k, w, c,
                      n_rows, (int)k, (const int32_t*)nullptr);
   return check_launch();
 }
@@ -3338,7 +3340,7 @@ int ddz_q_fc1_rows(int device, const float* dy, const int32_t* seg, const float*
   if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
-  hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(256), 0, (hipStream_t)stream, dy, (int64_t)QH, w2, d,
+  hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, dy, (int64_t)QH, w2, d,
                      (int64_t)0, QH, seg);
   return check_launch();
 }

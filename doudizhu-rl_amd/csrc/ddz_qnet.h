@@ -22,7 +22,18 @@
 constexpr int QN_TPB = 64;           // tables per block of the need kernels (four lanes per table)
 constexpr int QN_SEG_WORDS = 40;     // seg[0..15] first row of rank r's segment (multiples of FC_M), [15] = rows in use,
                                      // seg[16..31] first TILE of rank r, [31] = tiles in use, seg[32] = rows needed, [33] = overflow
-constexpr int FC_M = 256, FC_K = 16, FC_N = 256;   // k_fc1's tile: 256 rows x all 256 fc1 outputs, K in chunks of 16
+// k_fc1's geometry (compile-time; tools/fc1_probe.py builds and times the variants): FC_WAVES wavefronts per block, each
+// owning FC_TM x FC_TN tiles of 32 x 32; the block covers all 256 outputs, so FC_WN = 8 / FC_TN waves sit side by side and
+// the tile is FC_M = (FC_WAVES / FC_WN) * 32 * FC_TM rows; K in chunks of FC_K; FC_OCC blocks per CU (launch bounds)
+#ifndef DDZ_FC_WAVES
+#define DDZ_FC_WAVES 4
+#define DDZ_FC_TM 1
+#define DDZ_FC_TN 8
+#define DDZ_FC_KC 16
+#define DDZ_FC_OCC 2
+#endif
+constexpr int FC_WAVES = DDZ_FC_WAVES, FC_TM = DDZ_FC_TM, FC_TN = DDZ_FC_TN, FC_K = DDZ_FC_KC, FC_OCC = DDZ_FC_OCC, FC_N = 256;
+constexpr int FC_WN = 8 / FC_TN, FC_M = FC_WAVES / FC_WN * 32 * FC_TM;
 
 __device__ __forceinline__ uint64_t q_need_of_row(uint64_t nib) {
   // nibble c in 1..4 of rank r < 13 -> bit c - 1 of the same nibble (SWAR over the 13 nibbles); jokers -> bits 52, 53
@@ -283,19 +294,21 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;   // (native vectors: HIP's float4 struct arrays end up in scratch here)
 constexpr int FC_AS = FC_K + 1;      // LDS row stride of A (floats)
 constexpr int FC_BS = FC_N + 32;     // ... of B
-constexpr int FC_NA = FC_M * FC_K / 4 / 256, FC_NB = FC_K * FC_N / 4 / 256;   // float4 per thread and chunk: A FC_M x FC_K floats, B FC_K x 256
+constexpr int FC_THREADS = 64 * FC_WAVES;
+constexpr int FC_NA = FC_M * FC_K / 4 / FC_THREADS, FC_NB = FC_K * FC_N / 4 / FC_THREADS;   // float4 per thread and chunk
+static_assert(FC_NA >= 1 && FC_NB >= 1 && FC_M * FC_K / 4 % FC_THREADS == 0 && FC_K * FC_N / 4 % FC_THREADS == 0, "chunk / block shape");
 __device__ __forceinline__ void fc1_load(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t m0, int64_t M,
                                          int k0, int tid, f32x4 (&ra)[FC_NA], f32x4 (&rb)[FC_NB]) {
   // global -> registers: A row f / (FC_K / 4), k 4 (f % (FC_K / 4)); B row f / 64, columns 4 (f % 64)
 #pragma unroll
   for (int i = 0; i < FC_NA; ++i) {
-    const int f = tid + 256 * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
+    const int f = tid + FC_THREADS * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
     const int64_t m = m0 + row < M ? m0 + row : M - 1;   // (rows beyond M: some valid row, never stored -- no branch)
     ra[i] = *(const f32x4*)(A + m * lda + k0 + 4 * kq);
   }
 #pragma unroll
   for (int i = 0; i < FC_NB; ++i) {
-    const int f = tid + 256 * i, row = f >> 6, c4 = f & 63;
+    const int f = tid + FC_THREADS * i, row = f >> 6, c4 = f & 63;
     rb[i] = *(const f32x4*)(B + (int64_t)(k0 + row) * FC_N + 4 * c4);
   }
 }
@@ -303,51 +316,57 @@ __device__ __forceinline__ void fc1_stage(float* __restrict__ sA, float* __restr
                                           const f32x4 (&rb)[FC_NB]) {
 #pragma unroll
   for (int i = 0; i < FC_NA; ++i) {
-    const int f = tid + 256 * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
+    const int f = tid + FC_THREADS * i, row = f / (FC_K / 4), kq = f % (FC_K / 4);
     float* d = sA + row * FC_AS + 4 * kq;
     d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
   }
 #pragma unroll
   for (int i = 0; i < FC_NB; ++i) {
-    const int f = tid + 256 * i, row = f >> 6, c4 = f & 63;
+    const int f = tid + FC_THREADS * i, row = f >> 6, c4 = f & 63;
     *(f32x4*)(sB + row * FC_BS + 4 * c4) = rb[i];
   }
 }
-// one chunk of FC_K: wave (wm, wn) multiplies its 128 rows x 128 columns = 4 x 4 tiles of 32 x 32 -- per k-slice of 2 four A
-// and four B operand registers feed sixteen MFMAs; the operands of k-slice kk + 2 are read from LDS before the MFMAs of slice
-// kk are issued (explicit double buffer: an LDS read has 16 x 64 cycles of matrix work to land in)
-__device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const float* __restrict__ pb, f32x16 (&acc)[4][4]) {
-  float a0[4], b0[4], a1[4], b1[4];
+// one chunk of FC_K: a wave multiplies its FC_TM x FC_TN tiles of 32 x 32 -- per k-slice of 2, FC_TM + FC_TN operand registers
+// feed FC_TM x FC_TN MFMAs; the operands of k-slice kk + 2 are read from LDS before the MFMAs of slice kk are issued (explicit
+// double buffer: an LDS read has the slice's matrix work to land in)
+__device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const float* __restrict__ pb, f32x16 (&acc)[FC_TM][FC_TN]) {
+  float a0[FC_TM], b0[FC_TN], a1[FC_TM], b1[FC_TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { a0[i] = pa[32 * i * FC_AS]; b0[i] = pb[32 * i]; a1[i] = 0.f; b1[i] = 0.f; }
+  for (int i = 0; i < FC_TM; ++i) { a0[i] = pa[32 * i * FC_AS]; a1[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < FC_TN; ++j) { b0[j] = pb[32 * j]; b1[j] = 0.f; }
 #pragma unroll
   for (int kk = 0; kk < FC_K; kk += 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { a1[i] = pa[32 * i * FC_AS + kk + 2]; b1[i] = pb[(kk + 2) * FC_BS + 32 * i]; }
+    for (int i = 0; i < FC_TM; ++i) a1[i] = pa[32 * i * FC_AS + kk + 2];
+#pragma unroll
+    for (int j = 0; j < FC_TN; ++j) b1[j] = pb[(kk + 2) * FC_BS + 32 * j];
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the reads next to their MFMAs to save registers)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FC_TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FC_TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kk + 4 < FC_K) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a0[i] = pa[32 * i * FC_AS + kk + 4]; b0[i] = pb[(kk + 4) * FC_BS + 32 * i]; }
+      for (int i = 0; i < FC_TM; ++i) a0[i] = pa[32 * i * FC_AS + kk + 4];
+#pragma unroll
+      for (int j = 0; j < FC_TN; ++j) b0[j] = pb[(kk + 4) * FC_BS + 32 * j];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FC_TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FC_TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <bool ROWS>
-__global__ __launch_bounds__(256, 1) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
+__global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                          float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
   __shared__ float sA[2][FC_M * FC_AS];
   __shared__ __attribute__((aligned(16))) float sB[2][FC_K * FC_BS];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv / FC_WN, wn = wv % FC_WN;
   const int64_t m0 = (int64_t)blockIdx.x * FC_M;
   if (ROWS) {
     if ((int)blockIdx.x >= seg[31]) return;
@@ -359,17 +378,17 @@ __global__ __launch_bounds__(256, 1) void k_fc1(const float* __restrict__ A, int
   }
   f32x4 ra[FC_NA], rb[FC_NB];
   fc1_load(A, lda, B, m0, M, 0, tid, ra, rb);
-  f32x16 acc[4][4];
+  f32x16 acc[FC_TM][FC_TN];
   const int crow = 4 * (lane >> 5), ccol = lane & 31;   // C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FC_TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < FC_TN; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   fc1_stage(sA[0], sB[0], tid, ra, rb);
   __syncthreads();
-  const int oa = (128 * wm + (lane & 31)) * FC_AS + (lane >> 5), ob = (lane >> 5) * FC_BS + 128 * wn + (lane & 31);
+  const int oa = (32 * FC_TM * wm + (lane & 31)) * FC_AS + (lane >> 5), ob = (lane >> 5) * FC_BS + 32 * FC_TN * wn + (lane & 31);
   int cur = 0;
   for (int k0 = FC_K; k0 < K; k0 += FC_K) {
     // chunk k0 - FC_K is in LDS buffer `cur`; chunk k0 travels through the registers meanwhile and lands in the other
@@ -382,13 +401,13 @@ __global__ __launch_bounds__(256, 1) void k_fc1(const float* __restrict__ A, int
   }
   fc1_chunk(sA[cur] + oa, sB[cur] + ob, acc);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FC_TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < FC_TN; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int64_t row = m0 + 128 * wm + 32 * i + (g & 3) + 8 * (g >> 2) + crow;
-        const int col = 128 * wn + 32 * j + ccol;
+        const int64_t row = m0 + 32 * FC_TM * wm + 32 * i + (g & 3) + 8 * (g >> 2) + crow;
+        const int col = 32 * FC_TN * wn + 32 * j + ccol;
         if (row < M) C[row * FC_N + col] = ROWS ? acc[i][j][g] : acc[i][j][g] + C[row * FC_N + col];
       }
 }

@@ -132,7 +132,17 @@ import torch.nn as nn  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 _CONV_CH = 256
-FC_TILE = 256    # rows per tile of the engine's fc1 kernel (csrc/ddz_qnet.h FC_M): rank segments start at multiples of it
+_FC_TILE = None
+
+
+def fc_tile():
+    """rows per tile of the engine's fc1 kernel (ddz_q_fc1_tile_rows, csrc/ddz_qnet.h FC_M): the rank segments of the needed
+    rows start at multiples of it"""
+    global _FC_TILE
+    if _FC_TILE is None:
+        from . import _lib
+        _FC_TILE = int(_lib.lib().ddz_q_fc1_tile_rows())
+    return _FC_TILE
 
 
 class QNet(nn.Module):
@@ -363,12 +373,14 @@ class FactorisedQ:
 
     # ---- needed form: H0 per table from ONE dense GEMM + D only for the (rank, count) rows some legal move uses ----
     @torch.no_grad()
-    def needed(self, env, face, gemm="mfma"):
+    def needed(self, env, face, gemm="torch"):
         """face f32 [T,P,15,4] of env's CURRENT states (its slab lists are read on the device) -> NeededU: h0 f32 [T,256],
         d f32 [rows,256], row_index int32 [T,64], seg int32 [40] (device).  Nothing crosses to the host; every launch is
-        graph-capturable.  gemm = "mfma": both GEMMs by the engine's fp32 MFMA kernel (ddz_q_fc1_dense / _rows); "torch":
-        the dense one by torch.addmm (hipBLASLt), the rows by ddz_q_fc1_rows (a library GEMM would need the segment sizes
-        on the host).  The result aliases this object's workspace: consume it before the next call."""
+        graph-capturable.  The rows GEMM (D = dY x fc1[rank], segment sizes in device memory) is always the engine's fp32
+        MFMA kernel (ddz_q_fc1_rows: a library GEMM would need the sizes on the host).  The dense GEMM (a plain
+        [T, 3840] x [3840, 256] product) is torch.addmm = hipBLASLt by default (gemm="torch": 148 TFLOP/s in the loop), or
+        the same MFMA kernel (gemm="mfma", ddz_q_fc1_dense: 125 TFLOP/s; six geometries measured, tools/fc1_probe.py).
+        The result aliases this object's workspace: consume it before the next call."""
         from . import engine as E
         if self._ver != self._versions():
             self.refresh()
@@ -377,6 +389,7 @@ class FactorisedQ:
             raise ValueError(f"face must be a device tensor [T,{P},15,4] of the environment's tables")
         key = ("needed", face.device, T)
         if key not in self._ws:
+            FC_TILE = fc_tile()
             cap = (20 * T + 15 * FC_TILE + FC_TILE - 1) // FC_TILE * FC_TILE   # a move takes at most what the actor holds: <= 20 cards
             dev = face.device
             self._ws[key] = {"cap": cap, "y0": torch.zeros((T, 15 * H), dtype=torch.float32, device=dev),
@@ -417,12 +430,13 @@ class FactorisedQ:
     @torch.no_grad()
     def needed_torch(self, face, rows, offsets):
         """The same in plain torch from CSR lists (any device): the statement the engine's needed-rows kernels are tested
-        against -- same row layout (rank segments from multiples of FC_TILE, inside a segment table-major then count), so
+        against -- same row layout (rank segments from multiples of fc_tile(), inside a segment table-major then count), so
         row_index and seg compare exactly."""
         if self._ver != self._versions():
             self.refresh()
         T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
         dev = face.device
+        FC_TILE = fc_tile()
         need = self.need_sets(rows, offsets, T)                         # [T,15,4]
         per_rank = need.permute(1, 0, 2).reshape(15, T * 4)             # rank-major; inside a rank (t, c) order
         n_r = per_rank.sum(1)
@@ -557,13 +571,13 @@ class PolicyLoop:
     the host:
         face -> Q of every legal move of every table (slab layout) -> ddz_policy_step_slab (epsilon-greedy arg-max + apply +
         next lists + next face, ONE launch).
-    mode "needed" (default): FactorisedQ.needed -- the rows legal moves use, found on the device, both fc1 GEMMs on the
-        engine's fp32 MFMA kernel; nothing crosses to the host, every launch is graph-capturable (gemm="torch": the dense
-        GEMM by hipBLASLt instead);
+    mode "needed" (default): FactorisedQ.needed -- the rows legal moves use, found on the device; the per-rank rows GEMM on
+        the engine's fp32 MFMA kernel (segment sizes stay in device memory), the plain dense GEMM by hipBLASLt (gemm="mfma":
+        by the same MFMA kernel); nothing crosses to the host, every launch is graph-capturable;
     mode "packed": round 3's form (15 + cards-in-hand rows per table, fifteen library GEMMs, one 128-byte device -> host copy
         per iteration for their shapes); mode "full": all 69 rows per table, fixed shapes (packed=True / False select these)."""
 
-    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=None, mode=None, gemm="mfma"):
+    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=None, mode=None, gemm="torch"):
         from .engine import FACE_PLANES
         if FACE_PLANES[face_variant] != net.planes:
             raise ValueError("the network's input planes do not match the face variant")
@@ -586,8 +600,9 @@ class PolicyLoop:
     def describe(self):
         if self.mode == "needed":
             return ("ddz_q_need (the (rank, count) rows the legal moves use, on the device) -> ddz_q_features_needed (first "
-                    "layer: y0 per table + dY per needed row) -> ddz_q_fc1_dense (H0 = tab + y0 x Wd, K = 3840) + ddz_q_fc1_rows "
-                    "(D = dY x fc1[rank]) on the fp32 MFMA kernel k_fc1" + (" [dense GEMM: torch.addmm]" if self.gemm == "torch" else "")
+                    "layer: y0 per table + dY per needed row) -> H0 = tab + y0 x Wd (K = 3840: "
+                    + ("torch.addmm / hipBLASLt" if self.gemm == "torch" else "ddz_q_fc1_dense, the fp32 MFMA kernel k_fc1")
+                    + ") + ddz_q_fc1_rows (D = dY x fc1[rank], k_fc1 with the segment table in device memory)"
                     + " -> ddz_q_slab_needed -> ddz_policy_step_slab(greedy, face): every legal action of every table gets its Q "
                     "value each iteration; nothing crosses to the host")
         if self.mode == "packed":
@@ -676,7 +691,8 @@ class PolicyLoop:
         round 3's packed rows, fixed shapes."""
         out = {}
         T = self.env.T
-        for name, kw in (("needed_dense_gemm_by_hipblaslt", {"mode": "needed", "gemm": "torch"}),
+        other = "mfma" if self.gemm == "torch" else "torch"
+        for name, kw in (("needed_dense_gemm_by_" + ("k_fc1" if other == "mfma" else "hipblaslt"), {"mode": "needed", "gemm": other}),
                          ("packed_rows_round3", {"mode": "packed"}), ("fixed_shapes", {"mode": "full"})):
             loop = PolicyLoop(self.env, self.fq.net, face_variant=self.variant, epsilon=self.epsilon, **kw)
             loop.run(2)

@@ -26,7 +26,7 @@ def main(argv=None):
     ap.add_argument("--tables", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="needed", choices=("needed", "packed", "full"))
-    ap.add_argument("--gemm", default="mfma", choices=("mfma", "torch"))
+    ap.add_argument("--gemm", default="torch", choices=("mfma", "torch"), help="the plain dense GEMM: hipBLASLt (default) or the engine's k_fc1")
     ap.add_argument("--stages", action="store_true", help="also print the per-stage device times (HIP events)")
     a = ap.parse_args(argv)
     pkg = importlib.import_module("doudizhu-rl_amd")

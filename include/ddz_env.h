@@ -297,9 +297,9 @@ int ddz_q_slab_packed(ddz_env_t* env, const float* u, const int32_t* row_index, 
  *   D[row] = fc1_r^T (Y[t][r][c] - Y[t][r][0]), c >= 1             only for the (r, c) some LEGAL MOVE of table t takes
  * ddz_q_need: finds those (r, c) from the slab lists (counts / rows as ddz_step_slab left them) and lays their rows out in
  *   fifteen rank segments: row_index int32 [T][64] (columns as above; -1 = not needed) and seg int32 [40] (DEVICE memory:
- *   [r] first row of rank r's segment -- a multiple of 256 --, [15] rows in use, [16 + r] first 256-row tile of rank r, [31]
+ *   [r] first row of rank r's segment -- a multiple of the tile, ddz_q_fc1_tile_rows() = 128 --, [15] rows in use, [16 + r] first tile of rank r, [31]
  *   tiles in use, [32] rows needed, [33] 1 if row_capacity was too small -- then status bit 1 is raised and the rows that did
- *   not fit are -1).  row_capacity: rows of dy / d, a multiple of 256, >= 15 * 256; 20 T + 15 * 256 always suffices (a move
+ *   not fit are -1).  row_capacity: rows of dy / d, a multiple of the tile, >= 15 tiles; 20 T + 15 tiles always suffices (a move
  *   takes at most what the actor holds: <= 20 cards).  scratch: ddz_q_need_scratch_bytes(T) bytes, 256-byte aligned.
  * ddz_q_features_needed: the first layer (as ddz_q_features) into y0 f32 [T][15 * 256] (count 0 of every rank: the dense
  *   GEMM's left operand) and dy f32 [row_capacity][256] (Y[t][r][c] - Y[t][r][0] at the row of every needed (t, r, c)).
@@ -309,6 +309,7 @@ int ddz_q_slab_packed(ddz_env_t* env, const float* u, const int32_t* row_index, 
  * ddz_q_slab_needed: the per-row stage (as ddz_q_slab) from h0 f32 [T][256], d, row_index; a move whose (r, c) has no row
  *   (a list that does not belong to this row_index) contributes nothing for that rank and raises status bit 5.
  * fp32 throughout; results equal ddz_q_slab's up to summation order (tests: 1e-5 against the literal nn.Conv2d network). */
+int ddz_q_fc1_tile_rows(void);   /* rows per tile of the fc1 kernel: segment starts and row_capacity are multiples of it */
 int64_t ddz_q_need_scratch_bytes(int64_t n_tables);
 int ddz_q_need(ddz_env_t* env, const int32_t* counts, const int8_t* rows, int64_t stride, int64_t row_capacity, void* scratch,
                int64_t scratch_bytes, int32_t* row_index, int32_t* seg, void* stream);

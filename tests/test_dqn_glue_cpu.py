@@ -196,7 +196,7 @@ def test_packed_rows_hold_what_a_legal_move_can_use_and_give_the_same_q():
 def test_needed_rows_form_equals_the_literal_network():
     """FactorisedQ.needed_torch / q_csr_needed (the statement of the engine's needed-rows kernels, csrc/ddz_qnet.h): H0 per
     table from one dense product + a D row only for the (rank, count >= 1) pairs some move of the table's list uses.  The
-    layout: fifteen rank segments starting at multiples of the fc1 kernel's tile (256 rows), inside a segment table-major then count, every needed
+    layout: fifteen rank segments starting at multiples of the fc1 kernel's tile, inside a segment table-major then count, every needed
     (t, r, c) exactly one row, nothing else; q == the full factorised tables == the literal nn.Conv2d network (fp32, 1e-5
     absolute on outputs of magnitude ~0.1: summation order only)."""
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
@@ -219,7 +219,7 @@ def test_needed_rows_form_equals_the_literal_network():
         seg = nu.seg.tolist()
         used = nu.row_index[nu.row_index >= 0].long()
         assert used.unique().numel() == used.numel() == seg[32] == int(want_need.sum())
-        TILE = glue.FC_TILE
+        TILE = glue.fc_tile()
         assert all(seg[r] % TILE == 0 and seg[16 + r] == seg[r] // TILE for r in range(16)) and seg[0] == 0
         for r in range(15):
             cols = slice(4 * r, 4 * r + 4) if r < 13 else slice(52 + r - 13, 53 + r - 13)

@@ -22,7 +22,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("M,K", [(256, 16), (300, 256), (1000, 3840), (257, 48), (5, 32)])
+@pytest.mark.parametrize("M,K", [(256, 32), (300, 256), (1000, 3840), (257, 64), (5, 32)])
 def test_fc1_dense_is_an_exact_f32_gemm(pkg, M, K):
     """ddz_q_fc1_dense (k_fc1: v_mfma_f32_32x32x2_f32).  Integer-valued operands whose products and sums are exact in fp32:
     the result must EQUAL the integer product (an asymmetric B, rows beyond the last full tile, C added in); random fp32
@@ -45,7 +45,7 @@ def test_fc1_dense_is_an_exact_f32_gemm(pkg, M, K):
     bound = 2e-6 * (a.abs().double() @ w.abs().double()) + 1e-30
     assert bool(((c.cpu().double() - want).abs() <= bound).all())
     with pytest.raises(pkg.DdzError):
-        pkg.q_fc1_dense(torch.zeros((M, 24), device=_dev()), torch.zeros((24, 256), device=_dev()), c)   # K % 16 != 0
+        pkg.q_fc1_dense(torch.zeros((M, 24), device=_dev()), torch.zeros((24, 256), device=_dev()), c)   # K not a multiple of the chunk
 
 
 def _csr_of_slab(env):
@@ -69,7 +69,7 @@ def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, vari
         env.rollout_random(rounds) if rounds else None
         env.legal_slab()
         face = env.observe(variant)
-        nu = fq.needed(env, face)
+        nu = fq.needed(env, face, gemm="mfma")
         w = fq._ws[("needed", face.device, T)]
         off, rows, n = _csr_of_slab(env)
         ref = fqc.needed_torch(face.cpu(), rows.cpu(), off.cpu())
@@ -96,7 +96,7 @@ def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, vari
         with torch.no_grad():
             want = net_cpu(face.cpu()[seg_t[pick]], acts)[:, 0]
         assert float((q_csr[pick] - want).abs().max()) < 1e-5
-        assert used % glue.FC_TILE == 0 and used <= w["cap"]
+        assert used % glue.fc_tile() == 0 and used <= w["cap"]
         # the dense GEMM by the library gives the same H0 up to summation order
         nu2 = fq.needed(env, face, gemm="torch")
         assert float((nu2.h0.cpu() - ref.h0).abs().max()) < 1e-5
@@ -110,13 +110,13 @@ def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, vari
 
 def test_need_capacity_overflow_is_flagged_not_written(pkg):
     """row_capacity too small for the needed rows: status bit 1, seg[33] = 1, the rows that do not fit are -1 (never an
-    index beyond the capacity); a capacity that is no multiple of the fc1 tile (256 rows) is an argument error."""
+    index beyond the capacity); a capacity that is no multiple of the fc1 tile is an argument error."""
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
     engine = importlib.import_module("doudizhu-rl_amd.engine")
     T = 512
     env = pkg.BatchedEnv(T, seed=5, device=_dev())
     env.reset(); env.legal_slab()                            # 20-card leads: ~20 needed rows per table
-    cap = 15 * 256 + 1024
+    cap = 15 * glue.fc_tile() + 1024
     row_index = torch.full((T, 64), -1, dtype=torch.int32, device=_dev())
     seg = torch.zeros(40, dtype=torch.int32, device=_dev())
     scratch = torch.zeros(engine.q_need_scratch_bytes(T), dtype=torch.uint8, device=_dev())

@@ -117,18 +117,19 @@ def rollout_counters(d):
     return dict(disp[big]), trace[big]
 
 
-fetch, _ = rollout_counters("rollout/pmc_FETCH_SIZE")
-write, _ = rollout_counters("rollout/pmc_WRITE_SIZE")
-mix, ns = rollout_counters("rollout/pmc_mix")
-if fetch and write and mix:
-    old = json.load(open(os.path.join(P, "pmc_traffic.json")))
-    steps, steps_mix = 4096 * 2000, 4096 * 20000
+def rollout_entry(prefix, T, it_hbm, it_mix, old_mix):
+    fetch, _ = rollout_counters(f"rollout/{prefix}pmc_FETCH_SIZE")
+    write, _ = rollout_counters(f"rollout/{prefix}pmc_WRITE_SIZE")
+    mix, ns = rollout_counters(f"rollout/{prefix}pmc_mix")
+    if not (fetch and write and mix):
+        return None
+    steps, steps_mix = T * it_hbm, T * it_mix
     fk, wk = fetch["FETCH_SIZE"], write["WRITE_SIZE"]
-    out = {"k_rollout": {
+    return {
         "hbm_bytes_per_env_step": (2 * fk + wk) * 1024 / steps,
         "fetch_bytes_per_env_step": 2 * fk * 1024 / steps, "write_bytes_per_env_step": wk * 1024 / steps,
         "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "env_steps": steps,
-        "workload": "tools/run_rollout.py 4096 2000 (4096 tables, 2000 in-launch iterations, seed 0), round-4 kernel",
+        "workload": f"tools/run_rollout.py {T} {it_hbm} ({T} tables, {it_hbm} in-launch iterations, seed 0), round-4 kernel",
         "method": "tools/profile.sh rollout: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
                   "bytes = KB*1024, FETCH doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
                   "WRITE_SIZE taken as is (16-B-per-lane stores).  Every iteration overwrites the same state rows / list slab "
@@ -142,14 +143,24 @@ if fetch and write and mix:
             "GRBM_GUI_ACTIVE": mix["GRBM_GUI_ACTIVE"], "xcds": 8, "launch_ns": ns,
             "clock_GHz": mix["GRBM_GUI_ACTIVE"] / 8 / ns,
             "env_steps_per_s_in_this_launch": steps_mix / (ns * 1e-9),
-            "workload": "tools/run_rollout.py 4096 20000 (one launch, 81.92 M env steps), round-4 kernel"},
-        "valu_mix": old["k_rollout"].get("valu_mix")}}
-    json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-    v = out["k_rollout"]["valu"]
-    print("k_rollout per step: VALU %.1f SALU %.1f branch %.1f LDS %.1f; clock %.3f GHz; %.4g steps/s; HBM %.2f B/step; waiting %.0f %%" % (
-        v["SQ_INSTS_VALU_per_env_step"], v["SQ_INSTS_SALU_per_env_step"], v["SQ_INSTS_BRANCH_per_env_step"],
-        v["SQ_INSTS_LDS_per_env_step"], v["clock_GHz"], v["env_steps_per_s_in_this_launch"],
-        out["k_rollout"]["hbm_bytes_per_env_step"], 100 * v["SQ_WAIT_ANY_share_of_wave_cycles"]))
+            "workload": f"tools/run_rollout.py {T} {it_mix} (one launch, {steps_mix / 1e6:.2f} M env steps), round-4 kernel"},
+        "valu_mix": old_mix}
+
+
+old = json.load(open(os.path.join(P, "pmc_traffic.json")))
+fresh = {}
+for key, prefix, T, ih, im in (("k_rollout", "", 4096, 2000, 20000), ("k_rollout_65536", "big_", 65536, 500, 2000)):
+    e = rollout_entry(prefix, T, ih, im, old["k_rollout"].get("valu_mix"))
+    if e:
+        old[key] = e
+        fresh[key] = e
+        v = e["valu"]
+        print("%s per step: VALU %.1f SALU %.1f branch %.1f LDS %.1f; clock %.3f GHz; %.4g steps/s; HBM %.2f B/step; waiting %.0f %%" % (
+            key, v["SQ_INSTS_VALU_per_env_step"], v["SQ_INSTS_SALU_per_env_step"], v["SQ_INSTS_BRANCH_per_env_step"],
+            v["SQ_INSTS_LDS_per_env_step"], v["clock_GHz"], v["env_steps_per_s_in_this_launch"],
+            e["hbm_bytes_per_env_step"], 100 * v["SQ_WAIT_ANY_share_of_wave_cycles"]))
+if fresh:
+    json.dump(old, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 
 # ---- dqn: per kernel of the configs[2] loop -- duration, MFMA pipe busy share, clock, HBM bytes
 def per_kernel(d, names):
@@ -206,11 +217,13 @@ if dq:
 # ---- pmc_kernels.json: what bench.py's issue blocks replay (kept entries are refreshed, others stay)
 pk_path = os.path.join(P, "pmc_kernels.json")
 pk = json.load(open(pk_path)) if os.path.exists(pk_path) else {}
-t4 = json.load(open(os.path.join(P, "pmc_traffic.json")))["k_rollout"]["valu"]
-if fetch and write and mix:   # (only when this run held a fresh `rollout` pass)
-  pk["k_rollout"].update({"valu_per_unit": t4["SQ_INSTS_VALU_per_env_step"], "salu_per_unit": t4["SQ_INSTS_SALU_per_env_step"],
+for key in fresh:   # (only when this run held a fresh `rollout` pass)
+  t4 = fresh[key]["valu"]
+  pk.setdefault(key, dict(pk["k_rollout"]))
+  pk[key]["tables"] = 4096 if key == "k_rollout" else 65536
+  pk[key].update({"valu_per_unit": t4["SQ_INSTS_VALU_per_env_step"], "salu_per_unit": t4["SQ_INSTS_SALU_per_env_step"],
                         "branch_per_unit": t4["SQ_INSTS_BRANCH_per_env_step"], "wait_any_share": t4["SQ_WAIT_ANY_share_of_wave_cycles"],
-                        "clock_GHz": t4["clock_GHz"], "source": "profiles/pmc_traffic.json (pass `rollout`, 4096 tables: " + t4["workload"] + ")"})
+                        "clock_GHz": t4["clock_GHz"], "source": "profiles/pmc_traffic.json (pass `rollout`: " + t4["workload"] + ")"})
 if slab["kernels"]:
     for key, name in (("random_65536", "k_slab_random_65536"), ("random_4096", "k_slab_random_4096"), ("fused_65536", "k_slab_fused_65536")):
         k = slab["kernels"].get(key)

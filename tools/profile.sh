@@ -7,11 +7,12 @@
 #   slab       k_slab in the modes of bench.py's legs (step_slab(RANDOM) = k_slab<0,true>, fused policy step = k_slab<4,true>)
 #              at 65,536 and 4096 tables: kernel stats + two PMC passes (instructions / waits, LDS / issue)
 #   auto       the rule-agent loop (examples/config4_rule_opponent.py): kernel stats + two PMC passes of k_auto2
-#   dqn        configs[2] with the Q-network in the loop (examples/config3_dqn_inference.py): kernel stats
+#   dqn        configs[2] with the Q-network in the loop (examples/config3_dqn_inference.py): kernel stats, MFMA / wait counters,
+#              HBM counters (separate passes), per-stage HIP-event times
 #   secondary  k_observe<0..3>, k_mask, k_moves*: kernel stats + HBM counters
 #   probe      tools/valu_issue_probe.hip (VALU issue rates) + tools/dpp_probe.hip (DPP scan / reduction vs ds_bpermute)
 #   stamps     -DDDZ_STAMP builds: where k_slab's and k_auto2's waves spend their cycles (tools/stamp_slab.py, stamp_auto.py)
-# tools/collect_r03.py turns the raw output into the summaries tracked under profiles/ (tools/README.md maps each file).
+# tools/collect_r04.py turns the raw output into the summaries tracked under profiles/ (tools/README.md maps each file).
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -29,7 +30,10 @@ for pass in "$@"; do
       head -8 $O/bench_stats/p_kernel_stats.csv ;;
     rollout)
       for c in FETCH_SIZE WRITE_SIZE; do pmc $O/pmc_$c $c python3 tools/run_rollout.py 4096 2000; done
-      pmc $O/pmc_mix "$P1" python3 tools/run_rollout.py 4096 20000 ;;
+      pmc $O/pmc_mix "$P1" python3 tools/run_rollout.py 4096 20000
+      # the headline configuration (65,536 tables): the same three passes
+      for c in FETCH_SIZE WRITE_SIZE; do pmc $O/big_pmc_$c $c python3 tools/run_rollout.py 65536 500; done
+      pmc $O/big_pmc_mix "$P1" python3 tools/run_rollout.py 65536 2000 ;;
     slab)
       for T in 65536 4096; do
         for m in random fused; do
