@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restric
 // ---- 2. first layer for the needed rows ----------------------------------------------------------------------------------
 // As k_q_feat (ddz_engine.hip), writing  y0[t][r][c] = Y[t][r][0][c]  (dense [T][15 * 256]: the A operand of the K = 3840 GEMM)
 // and, for every needed (r, cnt >= 1) of the table,  dy[row][c] = Y[t][r][cnt][c] - Y[t][r][0][c]  at row = row_index[t][col].
+// (Two channels per thread as the halves of packed-fp32 registers -- 30 v_pk_fma_f32 instead of 60 v_fma_f32 per (table, rank),
+// the `face` value broadcast by op_sel, no moves, bit-identical results -- measured SLOWER: 524 against 481 us at 65,536 tables
+// (190 VGPRs: two waves per SIMD instead of four, and the packed instruction does not issue faster than two plain ones).)
 template <int P>
 __global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                       const float* __restrict__ bias, const float* __restrict__ acnt,
