@@ -176,7 +176,10 @@ def per_kernel(d, names):
         kern[r["Dispatch_Id"]] = r["Kernel_Name"]
     out = {}
     for key, match in names.items():
-        ids = [i for i, k in kern.items() if match in k]
+        lo, hi = 0, float("inf")
+        if isinstance(match, tuple):      # (substring, shortest, longest duration in ns): two uses of one library kernel
+            match, lo, hi = match
+        ids = [i for i, k in kern.items() if match in k and lo <= trace.get(i, 0) < hi]
         if not ids:
             continue
         ids = sorted(ids, key=lambda i: trace.get(i, 0))
@@ -190,8 +193,10 @@ def per_kernel(d, names):
 
 DQN_KERNELS = {"k_fc1<false> (dense, K = 3840)": "k_fc1<false>", "k_fc1<true> (needed rows)": "k_fc1<true>", "k_q_feat_needed<6>": "k_q_feat_needed",
                "k_q_slab_needed": "k_q_slab_needed", "k_q_need_mask": "k_q_need_mask", "k_q_need_scan": "k_q_need_scan",
-               "k_q_need_assign": "k_q_need_assign", "k_slab<4,true>": "k_slab<4, true>", "table term (hipBLASLt)": "Cijk_"}
+               "k_q_need_assign": "k_q_need_assign", "k_slab<4,true>": "k_slab<4, true>",
+               "dense GEMM H0 += y0 x Wd (hipBLASLt)": ("Cijk_", 400000, float("inf")), "table term (hipBLASLt)": ("Cijk_", 0, 400000)}
 dq = per_kernel("dqn/p_mfma", DQN_KERNELS)
+dq.update({k + " [--gemm mfma run]": v for k, v in per_kernel("dqn/p_mfma_k_fc1", {"k_fc1<false> (dense, K = 3840)": "k_fc1<false>"}).items()})
 fe, wr = per_kernel("dqn/pmc_FETCH_SIZE", DQN_KERNELS), per_kernel("dqn/pmc_WRITE_SIZE", DQN_KERNELS)
 if dq:
     for k, e in dq.items():

@@ -55,6 +55,7 @@ for pass in "$@"; do
     dqn)
       stats $O/stats python3 examples/config3_dqn_inference.py --iters 10
       pmc $O/p_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" python3 examples/config3_dqn_inference.py --iters 8
+      pmc $O/p_mfma_k_fc1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" python3 examples/config3_dqn_inference.py --iters 8 --gemm mfma
       for c in FETCH_SIZE WRITE_SIZE; do pmc $O/pmc_$c $c python3 examples/config3_dqn_inference.py --iters 6; done
       python3 examples/config3_dqn_inference.py --iters 20 --stages > $O/config3.txt 2>&1
       head -14 $O/stats/p_kernel_stats.csv; tail -3 $O/config3.txt ;;
