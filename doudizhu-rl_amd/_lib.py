@@ -67,12 +67,13 @@ SYMBOLS = {
     "ddz_q_fc1_tile_rows": (C.c_int, []),
     "ddz_q_need_scratch_bytes": (C.c_int64, [C.c_int64]),
     "ddz_q_need": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                             C.c_void_p]),
+                             C.c_void_p, C.c_void_p]),
     "ddz_q_features_needed": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddz_q_fc1_dense": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ddz_q_fc1_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "ddz_q_slab_needed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    "ddz_q_fc1_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p]),
+    "ddz_q_slab_needed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_action_table": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "ddz_pack_trajectory": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

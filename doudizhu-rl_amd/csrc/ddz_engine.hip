@@ -3284,9 +3284,9 @@ int64_t ddz_q_need_scratch_bytes(int64_t n_tables) {
 }
 
 int ddz_q_need(ddz_env_t* e, const int32_t* counts, const int8_t* rows, int64_t stride, int64_t row_capacity, void* scratch,
-               int64_t scratch_bytes, int32_t* row_index, int32_t* seg, void* stream) {
+               int64_t scratch_bytes, int32_t* row_index, int32_t* seg, uint8_t* row_cnt, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (!counts || !rows || !scratch || !row_index || !seg || stride < 1) return DDZ_EINVAL;
+  if (!counts || !rows || !scratch || !row_index || !seg || !row_cnt || stride < 1) return DDZ_EINVAL;
   if (!al(counts, 4) || !al(rows, 16) || !al(scratch, 256) || !al(row_index, 16) || !al(seg, 4)) return DDZ_EINVAL;
   if (row_capacity < 15 * FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
   if (scratch_bytes < ddz_q_need_scratch_bytes(e->T)) return DDZ_ECAP;
@@ -3299,7 +3299,7 @@ int ddz_q_need(ddz_env_t* e, const int32_t* counts, const int8_t* rows, int64_t 
   hipLaunchKernelGGL(k_q_need_mask, dim3((unsigned)nblk), dim3(256), 0, st, counts, (const uint4*)rows, stride, e->T, need, blk);
   hipLaunchKernelGGL(k_q_need_scan, dim3(1), dim3(256), 0, st, blk, nblk, seg, row_capacity);
   hipLaunchKernelGGL(k_q_need_assign, dim3((unsigned)nblk), dim3(256), 0, st, (const uint64_t*)need, e->T, (const int32_t*)blk,
-                     (const int32_t*)seg, row_index, e->sc.status);
+                     (const int32_t*)seg, row_index, row_cnt, e->sc.status);
   return check_launch();
 }
 
@@ -3330,35 +3330,38 @@ int ddz_q_fc1_dense(int device, const float* a, int64_t n_rows, int64_t k, const
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
   hipLaunchKernelGGL(k_fc1<false>, dim3((unsigned)((n_rows + FC_M - 1) / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, a, k, w, c,
-                     n_rows, (int)k, (const int32_t*)nullptr);
+                     n_rows, (int)k, (const int32_t*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr);
   return check_launch();
 }
 
-int ddz_q_fc1_rows(int device, const float* dy, const int32_t* seg, const float* w2, float* d, int64_t row_capacity, void* stream) {
-  if (!dy || !seg || !w2 || !d) return DDZ_EINVAL;
-  if (!al(dy, 16) || !al(w2, 16) || !al(d, 4) || !al(seg, 4)) return DDZ_EINVAL;
+int ddz_q_fc1_rows(int device, const float* dy, const int32_t* seg, const uint8_t* row_cnt, const float* w2, const float* z, float* d,
+                   int64_t row_capacity, void* stream) {
+  if (!dy || !seg || !w2 || !d || !z || !row_cnt) return DDZ_EINVAL;
+  if (!al(dy, 16) || !al(w2, 16) || !al(d, 4) || !al(seg, 4) || !al(z, 4)) return DDZ_EINVAL;
   if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
   hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, dy, (int64_t)QH, w2, d,
-                     (int64_t)0, QH, seg);
+                     (int64_t)0, QH, seg, z, row_cnt);
   return check_launch();
 }
 
-int ddz_q_slab_needed(ddz_env_t* e, const float* h0, const float* d, int64_t row_capacity, const int32_t* row_index, const float* z,
+int ddz_q_slab_needed(ddz_env_t* e, const float* h0, const float* d, int64_t row_capacity, const int32_t* row_index,
                       int64_t hidden, const float* w2, const float* b2, const int32_t* counts, const int8_t* rows, int64_t stride,
                       float* q, void* stream) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (!al(h0, 16) || !al(d, 16) || !al(z, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4) || !al(row_index, 4))
+  if (!al(h0, 16) || !al(d, 16) || !al(w2, 16) || !al(b2, 4) || !al(counts, 4) || !al(rows, 16) || !al(q, 4) || !al(row_index, 4))
     return DDZ_EINVAL;
-  if (!h0 || !d || !z || !w2 || !b2 || !counts || !rows || !q || !row_index || hidden != QH || stride < 1 || row_capacity < 1) return DDZ_EINVAL;
+  if (!h0 || !d || !w2 || !b2 || !counts || !rows || !q || !row_index || hidden != QH || stride < 1 || row_capacity < 1) return DDZ_EINVAL;
   DeviceGuard g(e->device);
   if (!g.ok) return DDZ_ENODEV;
+  // (64 tables per block at most: the blocks are the unit the hardware balances over the CUs, the tables inside a block are
+  // handed out by an LDS ticket)
   int64_t v = (e->T + 4095) / 4096;
-  const int tpw = (int)(v < 1 ? 1 : v > 8 ? 8 : v);
+  const int tpw = (int)(v < 1 ? 1 : v > 4 ? 4 : v);
   const int64_t per_block = (int64_t)WPB * tpw;
   hipLaunchKernelGGL(k_q_slab_needed, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
-                     (const float4*)h0, (const float4*)d, row_capacity, (const float4*)z, e->T, tpw, (const float4*)w2, b2, counts,
+                     (const float4*)h0, (const float4*)d, row_capacity, e->T, tpw, (const float4*)w2, b2, counts,
                      (const uint4*)rows, stride, q, row_index, e->sc.status);
   return check_launch();
 }

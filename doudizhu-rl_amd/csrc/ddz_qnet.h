@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void k_q_need_scan(int32_t* __restrict__ blk, 
 // row_index[t][64] (-1 = not needed): a wave stores 16 tables x 256 bytes = one 4-KB run.
 __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restrict__ need, int64_t T, const int32_t* __restrict__ blk,
                                                        const int32_t* __restrict__ seg, int32_t* __restrict__ row_index,
-                                                       int32_t* __restrict__ status) {
+                                                       uint8_t* __restrict__ row_cnt, int32_t* __restrict__ status) {
+  // (row_cnt, may be null: the count c of every needed row -- k_fc1<true> adds z[rank][c] to the row it computes)
   const int q = threadIdx.x & 3;
   const int64_t t = (int64_t)blockIdx.x * QN_TPB + (threadIdx.x >> 2);
   const uint64_t m = t < T ? need[t] : 0;
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restric
       int32_t row = seg[r] + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if ((m >> (4 * r + c)) & 1u) { if (row < hi) out[4 * i + c] = row; else dropped = true; ++row; }
+        if ((m >> (4 * r + c)) & 1u) {
+          if (row < hi) { out[4 * i + c] = row; if (row_cnt) row_cnt[row] = (uint8_t)(c + 1); }
+          else dropped = true;
+          ++row;
+        }
     }
   }
   if (q == 3) {
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restric
     for (int r = 13; r < 15; ++r)
       if ((m >> (52 + r - 13)) & 1u) {
         const int32_t row = seg[r] + blk[(int64_t)blockIdx.x * 16 + r] + (int32_t)q_need_field(ex, r);
-        if (row < seg[r + 1]) out[4 + r - 13] = row; else dropped = true;
+        if (row < seg[r + 1]) { out[4 + r - 13] = row; if (row_cnt) row_cnt[row] = 1; }
+        else dropped = true;
       }
   }
   int4* dst = (int4*)(row_index + t * QP_COLS + 16 * q);
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__
   const uint32_t nr = (uint32_t)dy_rows;
   for (int ti = 0; ti < nt; ++ti) {   // table-major: a table's fifteen count-0 rows are one 15-KB run of y0
     float* d0 = y0 + (tb + ti) * (15 * QH) + c;
-    for (int r = 0; r < 15; ++r) {
+#pragma unroll 3
+    for (int r = 0; r < 15; ++r) {   // (three ranks per trip: their LDS broadcasts and FMA chains interleave)
       float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -366,9 +373,13 @@ __device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const fl
 }
 template <bool ROWS>
 __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                          float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg) {
+                                                          float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg,
+                                                          const float* __restrict__ zfold, const uint8_t* __restrict__ row_cnt) {
+  // ROWS with zfold / row_cnt: D[row] = dY[row] x fc1[rank] + z[rank][count of the row] -- the weights-only term of the action
+  // plane rides on the row, so the row stage reads ONE 1-KB row per (move, rank) and keeps its LDS for the table's rows
   __shared__ float sA[2][FC_M * FC_AS];
   __shared__ __attribute__((aligned(16))) float sB[2][FC_K * FC_BS];
+  __shared__ float sZ[ROWS ? 5 * QH : 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv / FC_WN, wn = wv % FC_WN;
   const int64_t m0 = (int64_t)blockIdx.x * FC_M;
   if (ROWS) {
@@ -378,6 +389,8 @@ __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restr
     for (int q = 1; q < 15; ++q) r += (int)blockIdx.x >= seg[16 + q];
     B += (int64_t)r * QH * FC_N;
     M = seg[15];
+    if (zfold)
+      for (int i = tid; i < 5 * QH; i += FC_THREADS) sZ[i] = zfold[(int64_t)r * 5 * QH + i];   // (visible behind the first barrier)
   }
   f32x4 ra[FC_NA], rb[FC_NB];
   fc1_load(A, lda, B, m0, M, 0, tid, ra, rb);
@@ -406,95 +419,185 @@ __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restr
 #pragma unroll
   for (int i = 0; i < FC_TM; ++i)
 #pragma unroll
-    for (int j = 0; j < FC_TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int64_t row = m0 + 32 * FC_TM * wm + 32 * i + (g & 3) + 8 * (g >> 2) + crow;
-        const int col = 32 * FC_TN * wn + 32 * j + ccol;
-        if (row < M) C[row * FC_N + col] = ROWS ? acc[i][j][g] : acc[i][j][g] + C[row * FC_N + col];
+    for (int g = 0; g < 16; ++g) {
+      const int64_t row = m0 + 32 * FC_TM * wm + 32 * i + (g & 3) + 8 * (g >> 2) + crow;
+      int zoff = -1;
+      if (ROWS && zfold && row < M) {
+        uint32_t c = row_cnt[row];
+        zoff = (int)(c > 4u ? 0u : c) * QH;     // (padding rows carry whatever count: their result is never read)
       }
+#pragma unroll
+      for (int j = 0; j < FC_TN; ++j) {
+        const int col = 32 * FC_TN * wn + 32 * j + ccol;
+        if (row < M)
+          C[row * FC_N + col] = ROWS ? (zoff >= 0 ? acc[i][j][g] + sZ[zoff + col] : acc[i][j][g]) : acc[i][j][g] + C[row * FC_N + col];
+      }
+    }
 }
 
 // ---- 4. the per-row stage over the needed rows -------------------------------------------------------------------------------
-// q[t][j] = b2 + w2 . relu( H0[t] + sum over the ranks r move j touches of ( D[row_index[t][col(r, cnt)]] + Z[r][cnt] ) )
+// q[t][j] = b2 + w2 . relu( H0[t] + sum over the ranks r move j touches of D'[row_index[t][col(r, cnt)]] ),  D' = D + Z[r][cnt]
+// (the weights-only term of the action plane is folded into the row by k_fc1<true>).
 // One wavefront per table at a time (tpw consecutive tables per wave); the wave's four 16-lane rows work on FOUR MOVES at
-// once: lane l of a row owns hidden units {4 (l + 16 k) .. + 3, k = 0..3} (a 1-KB row of H0 / D / Z is four coalesced 256-byte
-// reads per 16 lanes), a move's dot product is reduced with four DPP row steps.  Z (75 KB, weights only) lives in LDS.  A
-// column that is not set (a list that does not belong to this row_index) or points beyond the buffer contributes nothing
-// and raises status bit 5.  (First version: one move per wave at a time, Z from L2: 409 us at 65,536 tables.)
+// once: lane l of a row owns hidden units {4 (l + 16 k) .. + 3, k = 0..3} (a 1-KB row of H0 / D = four coalesced 256-byte
+// reads per 16 lanes), a move's dot product is reduced with four DPP row steps.  THE TABLE'S NEEDED ROWS ARE READ ONCE: a
+// (rank, count) row is used by every move that takes that count of the rank (a single by every straight through it ...) -- 4 x
+// on average, and between two uses the row had left the caches (1.08 GB fetched for 0.26 GB of rows, profiles/r04_dqn_pmc.json:
+// the kernel ran at the speed of those re-reads).  The wave stages the first QS_ROWS needed rows of its table in LDS (slot =
+// rank of the row's column among the table's needed columns); rows beyond that come from memory as before.  A column that
+// is not set (a list that does not belong to this row_index) or points beyond the buffer contributes nothing and raises
+// status bit 5.
+constexpr int QS_ROWS = 8;    // needed rows of a table kept in the wave's LDS cache (8 KB per wave; mean 3.8 per table)
+constexpr int QS_BIG = 24;    // ... in the block's cache of a HEAVY table (a move takes what the actor holds: <= 20 rows)
+constexpr int QS_HEAVY_MOVES = 64;
+// the moves [j_first, n) of one table, four at a time (the wave's 16-lane rows), stepping j_step; rows cached in `cache`
+// (slot < ncache) or read from memory
+__device__ __forceinline__ void q_slab_moves(const float4* __restrict__ D, const uint4* __restrict__ lrow, float* __restrict__ qt, int n,
+                                             int j_first, int j_step, int32_t myidx, uint64_t needm, const float4 (&h0)[4],
+                                             const float4 (&w)[4], float bias, const float4 (*cache)[QH / 4], int ncache, int lane,
+                                             int32_t* __restrict__ status) {
+  const int l16 = lane & 15, quarter = lane >> 4;
+  uint4 row_cur = j_first + quarter < n ? lrow[j_first + quarter] : make_uint4(0, 0, 0, 0);   // (a row's 16 lanes read the same 16 bytes)
+  for (int j0 = j_first; j0 < n; j0 += j_step) {
+    const int j = j0 + quarter;
+    const bool have = j < n;
+    const uint64_t nib = have ? pack_row(row_cur) : 0;
+    if (j + j_step < n) row_cur = lrow[j + j_step];        // the next trip's move, in flight during this one
+    float4 h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = h0[k];
+    uint32_t tm = ge_mask(nib, 1);                        // the ranks this row's move touches
+    while (__ballot(tm != 0)) {                           // wave-uniform trip count: the row with the most ranks
+      const bool act = tm != 0;
+      const int r = act ? __builtin_ctz(tm) : 0;
+      uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
+      c = c > 4u ? 4u : c;
+      if (r >= 13 && c > 1u) c = 1u;
+      const int col = act ? qp_col(r, (int)c) : 63;       // (column 63 is never set)
+      const int32_t pr = __shfl(myidx, col);              // every lane active here
+      if (act) {
+        const bool ok = (needm >> col) & 1ull;
+        const int slot = __popcll(needm & ((1ull << col) - 1ull));
+        if (!ok) {
+          if (l16 == 0) atomicOr(status, 32);
+        } else if (slot < ncache) {
+          const float4* cr = cache[slot] + l16;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const float4 v = cr[16 * k]; h[k].x += v.x; h[k].y += v.y; h[k].z += v.z; h[k].w += v.w; }
+        } else {
+          const float4* dr = D + (int64_t)pr * (QH / 4) + l16;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const float4 v = dr[16 * k]; h[k].x += v.x; h[k].y += v.y; h[k].z += v.z; h[k].w += v.w; }
+        }
+      }
+      tm &= tm - 1;
+    }
+    float p = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      p += fmaxf(h[k].x, 0.f) * w[k].x + fmaxf(h[k].y, 0.f) * w[k].y + fmaxf(h[k].z, 0.f) * w[k].z + fmaxf(h[k].w, 0.f) * w[k].w;
+    // sum over the 16 lanes of the row: four DPP row shifts, the total lands in lane 15 of the row
+    p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x111, 0xf));
+    p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x112, 0xf));
+    p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x114, 0xf));
+    p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x118, 0xf));
+    if (have && l16 == 15) qt[j] = p + bias;
+  }
+}
 __global__ __launch_bounds__(TB, 4) void k_q_slab_needed(const float4* __restrict__ H0, const float4* __restrict__ D, int64_t d_rows,
-                                                        const float4* __restrict__ Z, int64_t T, int tpw, const float4* __restrict__ w2,
+                                                        int64_t T, int tpw, const float4* __restrict__ w2,
                                                         const float* __restrict__ b2, const int32_t* __restrict__ counts,
                                                         const uint4* __restrict__ rows, int64_t stride, float* __restrict__ q,
                                                         const int32_t* __restrict__ pidx, int32_t* __restrict__ status) {
-  __shared__ float4 sZ[75 * (QH / 4)];
-  for (int i = threadIdx.x; i < 75 * (QH / 4); i += TB) sZ[i] = Z[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, l16 = lane & 15, quarter = lane >> 4;
+  __shared__ float4 s_cache[WPB][QS_ROWS][QH / 4];
+  __shared__ float4 s_big[QS_BIG][QH / 4];
+  __shared__ int32_t s_heavy[WPB * 8];   // tables of this block left to the whole block (tpw <= 8)
+  __shared__ uint32_t s_nheavy, s_next;
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
   const int wv = (int)rfl(threadIdx.x >> 6);
-  const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
-  const int ntab = t0 < T ? (int)(T - t0 < tpw ? T - t0 : tpw) : 0;
+  if (threadIdx.x == 0) { s_nheavy = 0; s_next = WPB; }
+  __syncthreads();
+  const int64_t tb = (int64_t)blockIdx.x * WPB * tpw;    // the block's first table
+  const int nblk_tab = tb < T ? (int)(T - tb < (int64_t)WPB * tpw ? T - tb : (int64_t)WPB * tpw) : 0;   // ... and how many it has
+  float4 (*cache)[QH / 4] = s_cache[wv];
   float4 w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = w2[l16 + 16 * k];
   const float bias = b2[0];
-  for (int i = 0; i < ntab; ++i) {
-    const int64_t t = t0 + i;
-    int n = (int)rfl((uint32_t)counts[t]);
+  // ---- phase 1: the block's tables are handed out one by one (an LDS ticket: a table costs between one memory round trip
+  // and dozens -- with a fixed share per wave, half of the wave-slots of the launch stood idle behind the unluckiest wave of
+  // every block).  A HEAVY table -- more needed rows than the wave's cache holds, or a long list: a fresh deal's 20-card
+  // lead has ~20 rows and 70 .. 400 moves -- is left to phase 2.  The next table's list size and row_index travel while the
+  // current table is evaluated.
+  int cur = wv < nblk_tab ? wv : -1;                     // the first WPB tables need no ticket
+  int n_next = cur >= 0 ? counts[tb + cur] : 0;
+  int32_t idx_next = cur >= 0 ? pidx[(tb + cur) * QP_COLS + lane] : -1;
+  while (cur >= 0) {
+    const int64_t t = tb + cur;
+    int n = (int)rfl((uint32_t)n_next);
+    const int32_t myidx = idx_next;                     // lane L holds column L of the table's row_index
+    {
+      uint32_t nx = 0;
+      if (lane == 0) nx = atomicAdd(&s_next, 1u);
+      nx = rfl(nx);
+      cur = nx < (uint32_t)nblk_tab ? (int)nx : -1;
+      if (cur >= 0) { n_next = counts[tb + cur]; idx_next = pidx[(tb + cur) * QP_COLS + lane]; }
+    }
     if (n < 0 || n > stride) n = 0;
     if (n == 0) continue;
-    const uint4* lrow = rows + t * stride;
-    float* qt = q + t * stride;
-    const int32_t myidx = pidx[t * QP_COLS + lane];     // lane L holds column L of the table's row_index
+    const bool mine = (uint32_t)myidx < (uint32_t)d_rows;
+    const uint64_t needm = __ballot(mine);              // the table's needed columns (with a valid row)
+    if (__popcll(needm) > QS_ROWS || n > QS_HEAVY_MOVES) {
+      if (lane == 0) s_heavy[atomicAdd(&s_nheavy, 1u)] = (int32_t)(t - tb);
+      continue;
+    }
+    // stage the needed rows: slot s = the s-th set column.  ALL loads are issued before the first one is stored (a
+    // load-store pair per trip would cost a memory round trip per row)
+    float4 h0[4];
+    {
+      uint64_t m = needm;
+      float4 tmp[QS_ROWS];
+#pragma unroll
+      for (int s_ = 0; s_ < QS_ROWS; ++s_) {
+        const bool on = m != 0;                           // wave-uniform
+        const int col = on ? __builtin_ctzll(m) : 0;
+        const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, col);
+        tmp[s_] = on ? D[(int64_t)pr * (QH / 4) + lane] : make_float4(0.f, 0.f, 0.f, 0.f);   // one coalesced 1-KB read
+        m &= m - 1;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h0[k] = H0[t * (QH / 4) + l16 + 16 * k];
+      __builtin_amdgcn_wave_barrier();                  // (the previous table's reads of the cache are done: same wave, in order)
+#pragma unroll
+      for (int s_ = 0; s_ < QS_ROWS; ++s_) cache[s_][lane] = tmp[s_];
+      __builtin_amdgcn_wave_barrier();
+    }
+    q_slab_moves(D, rows + t * stride, q + t * stride, n, 0, 4, myidx, needm, h0, w, bias, cache, QS_ROWS, lane, status);
+  }
+  __syncthreads();
+  // ---- phase 2: the block's heavy tables, one after the other, by ALL its waves: the rows staged once in the block's cache
+  // (wave w loads rows w, w + 16), wave w evaluates moves 4 w .. 4 w + 3, then + 64, ...
+  const int nheavy = (int)s_nheavy;                      // (block-uniform)
+  for (int hi = 0; hi < nheavy; ++hi) {
+    const int64_t t = tb + s_heavy[hi];
+    int n = counts[t];
+    if (n < 0 || n > stride) n = 0;
+    const int32_t myidx = pidx[t * QP_COLS + lane];
+    const bool mine = (uint32_t)myidx < (uint32_t)d_rows;
+    const uint64_t needm = __ballot(mine);
+    for (int s_ = wv; s_ < QS_BIG; s_ += WPB) {          // the s-th set column, if there is one
+      uint64_t m = needm;
+      for (int k = 0; k < s_ && m; ++k) m &= m - 1;
+      if (m) {
+        const int32_t pr = (int32_t)__builtin_amdgcn_readlane(myidx, __builtin_ctzll(m));
+        s_big[s_][lane] = D[(int64_t)pr * (QH / 4) + lane];
+      }
+    }
     float4 h0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) h0[k] = H0[t * (QH / 4) + l16 + 16 * k];
-    for (int j0 = 0; j0 < n; j0 += 4) {
-      const int j = j0 + quarter;
-      const bool have = j < n;
-      const uint64_t nib = have ? pack_row(lrow[j]) : 0;   // (the 16 lanes of a row read the same 16 bytes)
-      float4 h[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) h[k] = h0[k];
-      uint32_t tm = ge_mask(nib, 1);                        // the ranks this row's move touches
-      while (__ballot(tm != 0)) {                           // wave-uniform trip count: the row with the most ranks
-        const bool act = tm != 0;
-        const int r = act ? __builtin_ctz(tm) : 0;
-        uint32_t c = (uint32_t)(nib >> (4 * r)) & 15u;
-        c = c > 4u ? 4u : c;
-        if (r >= 13 && c > 1u) c = 1u;
-        const int col = act ? qp_col(r, (int)c) : 63;       // (column 63 is never set)
-        const int32_t pr = __shfl(myidx, col);              // every lane active here
-        if (act) {
-          const float4* zr = sZ + (r * 5 + (int)c) * (QH / 4) + l16;
-          if ((uint32_t)pr < (uint32_t)d_rows) {
-            const float4* dr = D + (int64_t)pr * (QH / 4) + l16;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float4 v = dr[16 * k], zz = zr[16 * k];
-              h[k].x += v.x + zz.x; h[k].y += v.y + zz.y; h[k].z += v.z + zz.z; h[k].w += v.w + zz.w;
-            }
-          } else {
-            if (l16 == 0) atomicOr(status, 32);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float4 zz = zr[16 * k];
-              h[k].x += zz.x; h[k].y += zz.y; h[k].z += zz.z; h[k].w += zz.w;
-            }
-          }
-        }
-        tm &= tm - 1;
-      }
-      float p = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        p += fmaxf(h[k].x, 0.f) * w[k].x + fmaxf(h[k].y, 0.f) * w[k].y + fmaxf(h[k].z, 0.f) * w[k].z + fmaxf(h[k].w, 0.f) * w[k].w;
-      // sum over the 16 lanes of the row: four DPP row shifts, the total lands in lane 15 of the row
-      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x111, 0xf));
-      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x112, 0xf));
-      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x114, 0xf));
-      p += __int_as_float(DDZ_DPP(0, __float_as_int(p), 0x118, 0xf));
-      if (have && l16 == 15) qt[j] = p + bias;
-    }
+    __syncthreads();
+    q_slab_moves(D, rows + t * stride, q + t * stride, n, 4 * wv, 4 * WPB, myidx, needm, h0, w, bias, s_big, QS_BIG, lane, status);
+    __syncthreads();                                     // (the cache is free for the next heavy table)
   }
 }

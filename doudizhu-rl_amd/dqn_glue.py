@@ -398,9 +398,10 @@ class FactorisedQ:
                              "h0": torch.zeros((T, H1), dtype=torch.float32, device=dev),
                              "row_index": torch.full((T, 64), -1, dtype=torch.int32, device=dev),
                              "seg": torch.zeros(40, dtype=torch.int32, device=dev),
+                             "row_cnt": torch.zeros(cap, dtype=torch.uint8, device=dev),
                              "scratch": torch.zeros(E.q_need_scratch_bytes(T), dtype=torch.uint8, device=dev)}
         w = self._ws[key]
-        env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"])
+        env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"])
         E.q_features_needed(face, self.Wf, self.bias_f, self.A, w["row_index"], w["y0"], w["dy"])
         torch.addmm(self.base, face.view(T, P * 60), self.Mz_f, out=w["h0"])      # the per-table term (K = 60 P: small)
         if gemm == "mfma":
@@ -409,7 +410,7 @@ class FactorisedQ:
             w["h0"].addmm_(w["y0"], self.Wd)
         else:
             raise ValueError("gemm must be 'mfma' or 'torch'")
-        E.q_fc1_rows(w["dy"], w["seg"], self.W2, w["d"])
+        E.q_fc1_rows(w["dy"], w["seg"], w["row_cnt"], self.W2, self.Z, w["d"])     # D = dY x fc1[rank] + Z[rank][count]
         return NeededU(w["h0"], w["d"], w["row_index"], w["seg"])
 
     @staticmethod
@@ -463,6 +464,9 @@ class FactorisedQ:
                 m = dst >= 0
                 dy[dst[m]] = Y[r, c][m] - Y[r, 0][m]
             d[starts[r]: starts[r] + int(n_r[r])] = dy[starts[r]: starts[r] + int(n_r[r])] @ self.W2[r]
+            for c in range(1, 5 if r < 13 else 2):                      # the action plane's own term rides on the row
+                dst = idx[:, r, c - 1]
+                d[dst[dst >= 0]] += self.Z[r, c]
         h0 = torch.addmm(self.base, face.reshape(T, P * 60), self.Mz_f) + y0 @ self.Wd
         nu = NeededU(h0, d, row_index, seg)
         nu.y0, nu.dy = y0, dy
@@ -481,8 +485,8 @@ class FactorisedQ:
         col = torch.where(r[None, :] < 13, 4 * r[None, :] + cnt - 1, 52 + (r[None, :] - 13)).clamp(min=0)
         prow = nu.row_index.long()[seg[:, None], col]                   # [N,15]
         use = (cnt > 0) & (prow >= 0)
-        dsum = (nu.d[prow.clamp(min=0)] * use[:, :, None]).sum(1)
-        h = nu.h0[seg] + dsum + F.embedding_bag(r[None, :] * 5 + cnt, self.Z.view(-1, self.H1), mode="sum")
+        dsum = (nu.d[prow.clamp(min=0)] * use[:, :, None]).sum(1)    # (Z[r][cnt] is part of the row)
+        h = nu.h0[seg] + dsum
         return F.relu(h) @ self.w2 + self.b2
 
     def _first_layer_torch(self, face):
@@ -531,7 +535,7 @@ class FactorisedQ:
         """The per-row stage over the engine's slab lists (ddz_q_slab): q f32 [T, stride], entries beyond counts[t]
         untouched.  Feeds env.policy_step_slab / select_slab."""
         if isinstance(U, NeededU):
-            return env.q_slab_needed(U.h0, U.d, U.row_index, self.Z, self.w2, self.b2, out=out)
+            return env.q_slab_needed(U.h0, U.d, U.row_index, self.w2, self.b2, out=out)
         if isinstance(U, PackedU):
             return env.q_slab_packed(U.u, U.row_index, U.rank_row0, U.table_term, self.Z, self.w2, self.b2, out=out)
         return env.q_slab(U, self.Z, self.w2, self.b2, out=out)
@@ -548,7 +552,8 @@ class PackedU:
 
 class NeededU:
     """FactorisedQ.needed's result: h0 f32 [T,256] (fc1's pre-activation of the pass: every count 0), d f32 [rows,256] (what a
-    needed (rank, count >= 1) adds to it), row_index int32 [T,64], seg int32 [40] (device: segment starts, rows in use)."""
+    needed (rank, count >= 1) adds to it, the action plane's weights-only term Z[rank][count] included), row_index int32
+    [T,64], seg int32 [40] (device: segment starts, rows in use)."""
     __slots__ = ("h0", "d", "row_index", "seg", "y0", "dy")
 
     def __init__(self, h0, d, row_index, seg):
@@ -651,15 +656,15 @@ class PolicyLoop:
         self.q_values()                                                   # (workspace exists)
         w = fq._ws[("needed", self.face.device, T)]
         for _ in range(int(n)):
-            timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"]))
+            timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"]))
             timed("features", lambda: E.q_features_needed(self.face, fq.Wf, fq.bias_f, fq.A, w["row_index"], w["y0"], w["dy"]))
             timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
             if self.gemm == "mfma":
                 timed("fc1_dense", lambda: E.q_fc1_dense(w["y0"], fq.Wd, w["h0"]))
             else:
                 timed("fc1_dense", lambda: w["h0"].addmm_(w["y0"], fq.Wd))
-            timed("fc1_rows", lambda: E.q_fc1_rows(w["dy"], w["seg"], fq.W2, w["d"]))
-            timed("row_stage", lambda: env.q_slab_needed(w["h0"], w["d"], w["row_index"], fq.Z, fq.w2, fq.b2, out=self.q))
+            timed("fc1_rows", lambda: E.q_fc1_rows(w["dy"], w["seg"], w["row_cnt"], fq.W2, fq.Z, w["d"]))
+            timed("row_stage", lambda: env.q_slab_needed(w["h0"], w["d"], w["row_index"], fq.w2, fq.b2, out=self.q))
             seg = w["seg"].cpu()
             rows_needed += int(seg[32]); rows_padded += int(seg[15]); moves += int(env.counts.sum())
             timed("env_step", lambda: env.policy_step_slab(self.q, self.epsilon, face_variant=self.variant, face_out=self.face,

@@ -316,19 +316,21 @@ class BatchedEnv:
         return out
 
     # ---- the needed-rows form of the ragged Q forward (csrc/ddz_qnet.h; dqn_glue.FactorisedQ.needed) ----
-    def q_need(self, row_capacity, scratch, row_index, seg):
+    def q_need(self, row_capacity, scratch, row_index, seg, row_cnt):
         """ddz_q_need: which (rank, count >= 1) rows the CURRENT slab lists use, per table, laid out in rank segments:
-        writes row_index int32 [T,64] and seg int32 [40] (device); nothing crosses to the host."""
+        writes row_index int32 [T,64], seg int32 [40] and row_cnt uint8 [row_capacity] (device); nothing crosses to the host."""
         if not self._slab_fresh:
             self.legal_slab()
         if (row_index.dtype != torch.int32 or tuple(row_index.shape) != (self.T, 64) or not row_index.is_contiguous()
-                or seg.dtype != torch.int32 or seg.numel() < 40 or scratch.dtype != torch.uint8):
-            raise ValueError("row_index must be int32 [T,64], seg int32 [40], scratch uint8")
+                or seg.dtype != torch.int32 or seg.numel() < 40 or scratch.dtype != torch.uint8
+                or row_cnt.dtype != torch.uint8 or row_cnt.numel() < int(row_capacity)):
+            raise ValueError("row_index must be int32 [T,64], seg int32 [40], scratch uint8, row_cnt uint8 [row_capacity]")
         check(self.lib.ddz_q_need(self._h, self._pp["counts"], self._pp["rows"], self.slab_stride, int(row_capacity),
-                                  _p(scratch), scratch.numel(), _p(row_index), _p(seg), _stream(self.device)))
+                                  _p(scratch), scratch.numel(), _p(row_index), _p(seg), _p(row_cnt), _stream(self.device)))
 
-    def q_slab_needed(self, h0, d, row_index, z, w2, b2, out=None):
-        """ddz_q_slab_needed: q f32 [T, stride] of every legal move from h0 f32 [T,256], d f32 [rows,256], row_index."""
+    def q_slab_needed(self, h0, d, row_index, w2, b2, out=None):
+        """ddz_q_slab_needed: q f32 [T, stride] of every legal move from h0 f32 [T,256], d f32 [rows,256] (with z folded in by
+        q_fc1_rows), row_index."""
         if not self._slab_fresh:
             self.legal_slab()
         H = int(h0.shape[-1])
@@ -339,7 +341,7 @@ class BatchedEnv:
             out = torch.zeros((self.T, self.slab_stride), dtype=torch.float32, device=self.device)
         elif out.dtype != torch.float32 or out.numel() != self.T * self.slab_stride or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32 [T, stride] tensor")
-        check(self.lib.ddz_q_slab_needed(self._h, _p(h0), _p(d), int(d.shape[0]), _p(row_index), _p(z), H, _p(w2), _p(b2),
+        check(self.lib.ddz_q_slab_needed(self._h, _p(h0), _p(d), int(d.shape[0]), _p(row_index), H, _p(w2), _p(b2),
                                          self._pp["counts"], self._pp["rows"], self.slab_stride, _p(out), _stream(self.device)))
         return out
 
@@ -657,8 +659,9 @@ def q_fc1_dense(a, w, c):
     return c
 
 
-def q_fc1_rows(dy, seg, w2, d):
-    """ddz_q_fc1_rows: d[row] = dy[row] @ w2[rank of the row] for the rows / rank segments of seg (device int32 [40])."""
+def q_fc1_rows(dy, seg, row_cnt, w2, z, d):
+    """ddz_q_fc1_rows: d[row] = dy[row] @ w2[rank of the row] + z[rank][row_cnt[row]] for the rows / rank segments of seg
+    (device int32 [40]); z f32 [15,5,256]."""
     L = _lib.lib()
     dev = _require_gpu(dy.device)
     n = int(dy.shape[0])
@@ -667,7 +670,10 @@ def q_fc1_rows(dy, seg, w2, d):
             raise ValueError("dy / d [rows,256], w2 [15,256,256]: contiguous float32 tensors on one device")
     if seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
         raise ValueError("seg must be int32 [40] on the same device")
-    check(L.ddz_q_fc1_rows(dev.index, _p(dy), _p(seg), _p(w2), _p(d), n, _stream(dev)))
+    if (row_cnt.dtype != torch.uint8 or row_cnt.numel() < n or row_cnt.device != dev or z.dtype != torch.float32
+            or z.numel() != 75 * 256 or not z.is_contiguous() or z.device != dev):
+        raise ValueError("row_cnt must be uint8 [rows], z float32 [15,5,256], on the same device")
+    check(L.ddz_q_fc1_rows(dev.index, _p(dy), _p(seg), _p(row_cnt), _p(w2), _p(z), _p(d), n, _stream(dev)))
     return d
 
 

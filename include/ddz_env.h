@@ -292,33 +292,37 @@ int ddz_q_slab_packed(ddz_env_t* env, const float* u, const int32_t* row_index, 
 
 /* The same forward over NEEDED rows only -- nothing on the host, no host-side sizes (doudizhu-rl_amd/csrc/ddz_qnet.h;
  * BASELINE configs[2]: net.py inference in the loop, game.py:95-104 / dqn.py:56,67 for every table at once):
- *   fc1 pre-activation of move j of table t = H0[t] + sum over the ranks r the move touches of (D[row(t, r, cnt_jr)] + z[r][cnt_jr])
+ *   fc1 pre-activation of move j of table t = H0[t] + sum over the ranks r the move touches of D[row(t, r, cnt_jr)]
  *   H0[t] = table_term[t] + sum_r fc1_r^T Y[t][r][0]               one dense GEMM, K = 15 * 256
- *   D[row] = fc1_r^T (Y[t][r][c] - Y[t][r][0]), c >= 1             only for the (r, c) some LEGAL MOVE of table t takes
+ *   D[row] = fc1_r^T (Y[t][r][c] - Y[t][r][0]) + z[r][c], c >= 1   only for the (r, c) some LEGAL MOVE of table t takes
  * ddz_q_need: finds those (r, c) from the slab lists (counts / rows as ddz_step_slab left them) and lays their rows out in
  *   fifteen rank segments: row_index int32 [T][64] (columns as above; -1 = not needed) and seg int32 [40] (DEVICE memory:
  *   [r] first row of rank r's segment -- a multiple of the tile, ddz_q_fc1_tile_rows() = 128 --, [15] rows in use, [16 + r] first tile of rank r, [31]
  *   tiles in use, [32] rows needed, [33] 1 if row_capacity was too small -- then status bit 1 is raised and the rows that did
- *   not fit are -1).  row_capacity: rows of dy / d, a multiple of the tile, >= 15 tiles; 20 T + 15 tiles always suffices (a move
+ *   not fit are -1); row_cnt uint8 [row_capacity]: the count c of every needed row (ddz_q_fc1_rows adds z[rank][c]).
+ *   row_capacity: rows of dy / d, a multiple of the tile, >= 15 tiles; 20 T + 15 tiles always suffices (a move
  *   takes at most what the actor holds: <= 20 cards).  scratch: ddz_q_need_scratch_bytes(T) bytes, 256-byte aligned.
  * ddz_q_features_needed: the first layer (as ddz_q_features) into y0 f32 [T][15 * 256] (count 0 of every rank: the dense
  *   GEMM's left operand) and dy f32 [row_capacity][256] (Y[t][r][c] - Y[t][r][0] at the row of every needed (t, r, c)).
  * ddz_q_fc1_dense: c f32 [n_rows][256] += a f32 [n_rows][k] x w f32 [k][256] (k a multiple of 16); ddz_q_fc1_rows:
- *   d[row] = dy[row] x w2[rank of the row] (w2 f32 [15][256][256], input-major), rows and ranks from seg -- both one launch
+ *   d[row] = dy[row] x w2[rank of the row] + z[rank][row_cnt[row]] (w2 f32 [15][256][256], input-major; z f32 [15][5][256]: the
+ *   action plane's own path through conv_shunzi and fc1, weights only), rows and ranks from seg -- both one launch
  *   of a hand-written fp32 MFMA kernel (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain; no library GEMM).
- * ddz_q_slab_needed: the per-row stage (as ddz_q_slab) from h0 f32 [T][256], d, row_index; a move whose (r, c) has no row
+ * ddz_q_slab_needed: the per-row stage (as ddz_q_slab) from h0 f32 [T][256], d, row_index (a table's needed rows are staged in
+ *   LDS once: every move that takes that count of the rank uses the row); a move whose (r, c) has no row
  *   (a list that does not belong to this row_index) contributes nothing for that rank and raises status bit 5.
  * fp32 throughout; results equal ddz_q_slab's up to summation order (tests: 1e-5 against the literal nn.Conv2d network). */
 int ddz_q_fc1_tile_rows(void);   /* rows per tile of the fc1 kernel: segment starts and row_capacity are multiples of it */
 int64_t ddz_q_need_scratch_bytes(int64_t n_tables);
 int ddz_q_need(ddz_env_t* env, const int32_t* counts, const int8_t* rows, int64_t stride, int64_t row_capacity, void* scratch,
-               int64_t scratch_bytes, int32_t* row_index, int32_t* seg, void* stream);
+               int64_t scratch_bytes, int32_t* row_index, int32_t* seg, uint8_t* row_cnt, void* stream);
 int ddz_q_features_needed(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
                           const float* acnt, const int32_t* row_index, float* y0, float* dy, int64_t row_capacity, void* stream);
 int ddz_q_fc1_dense(int device_id, const float* a, int64_t n_rows, int64_t k, const float* w, float* c, void* stream);
-int ddz_q_fc1_rows(int device_id, const float* dy, const int32_t* seg, const float* w2, float* d, int64_t row_capacity, void* stream);
+int ddz_q_fc1_rows(int device_id, const float* dy, const int32_t* seg, const uint8_t* row_cnt, const float* w2, const float* z,
+                   float* d, int64_t row_capacity, void* stream);
 int ddz_q_slab_needed(ddz_env_t* env, const float* h0, const float* d, int64_t row_capacity, const int32_t* row_index,
-                      const float* z, int64_t hidden, const float* w2, const float* b2, const int32_t* counts, const int8_t* rows,
+                      int64_t hidden, const float* w2, const float* b2, const int32_t* counts, const int8_t* rows,
                       int64_t stride, float* q, void* stream);
 
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id

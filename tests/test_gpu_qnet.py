@@ -104,7 +104,7 @@ def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, vari
     # a row_index that does not belong to the lists: nothing is dereferenced beyond the buffers, status bit 5
     wild = nu.row_index.clone()
     wild[wild >= 0] += w["cap"]
-    qw = env.q_slab_needed(nu.h0, nu.d, wild, fq.Z, fq.w2, fq.b2)
+    qw = env.q_slab_needed(nu.h0, nu.d, wild, fq.w2, fq.b2)
     assert bool(torch.isfinite(qw[valid]).all()) and env.status() & 32
 
 
@@ -120,12 +120,20 @@ def test_need_capacity_overflow_is_flagged_not_written(pkg):
     row_index = torch.full((T, 64), -1, dtype=torch.int32, device=_dev())
     seg = torch.zeros(40, dtype=torch.int32, device=_dev())
     scratch = torch.zeros(engine.q_need_scratch_bytes(T), dtype=torch.uint8, device=_dev())
-    env.q_need(cap, scratch, row_index, seg)
+    row_cnt = torch.zeros(cap + 64, dtype=torch.uint8, device=_dev())
+    env.q_need(cap, scratch, row_index, seg, row_cnt)
     s = seg.cpu().tolist()
     assert s[33] == 1 and s[15] <= cap and s[32] > cap and int(row_index.max()) < cap
     assert env.status() & 2
+    # the count of every row that exists, nothing behind the capacity
+    idx = row_index.cpu()
+    cnt = row_cnt.cpu()
+    col = torch.arange(64)
+    want_c = torch.where(col < 52, col % 4 + 1, torch.ones_like(col))
+    sel = idx >= 0
+    assert bool((cnt[idx[sel].long()] == want_c[None, :].expand_as(idx)[sel].to(torch.uint8)).all()) and int(cnt[cap:].max()) == 0
     with pytest.raises(pkg.DdzError):
-        env.q_need(cap + 5, scratch, row_index, seg)
+        env.q_need(cap + 5, scratch, row_index, seg, row_cnt)
     assert glue is not None
 
 
