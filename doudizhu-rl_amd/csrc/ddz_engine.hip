@@ -890,21 +890,23 @@ struct RolloutArgs {
 
 // STAGED (ddz_rollout_random_csr_staged): iteration j of the launch writes its lists into slab j (a template parameter: the
 // per-iteration address arithmetic costs the plain rollout 12 % when it is a run-time option).
-template <bool IDS, bool TRAJ, bool STAGED = false>
-__global__ __launch_bounds__(TB, 4) void k_rollout(RolloutArgs a) {
+// RW = wavefronts per block: 16 (one block per CU: 4 waves per SIMD), or 12 for the variants that fit 85 VGPRs -- two blocks of
+// 74 KB per CU = 6 waves per SIMD (round 4: the kernel waits a third of its wave cycles; more waves in flight cover them).
+template <bool IDS, bool TRAJ, bool STAGED = false, int RW = WPB>
+__global__ __launch_bounds__(RW * 64, RW == WPB ? 4 : 6) void k_rollout(RolloutArgs a) {
   Stamps<12> stamps;
   __shared__ HotTabT<false> hot;
-  __shared__ uint64_t s_stage[WPB][STAGE_CAP];
-  __shared__ uint16_t s_svl[WPB][STAGE_CAP];
-  __shared__ uint16_t s_sid[IDS ? WPB : 1][IDS ? STAGE_CAP : 1];
+  __shared__ uint64_t s_stage[RW][STAGE_CAP];
+  __shared__ uint16_t s_svl[RW][STAGE_CAP];
+  __shared__ uint16_t s_sid[IDS ? RW : 1][IDS ? STAGE_CAP : 1];
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
-  const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
+  const int64_t wave = (int64_t)blockIdx.x * RW + wv;
   const int64_t t0 = wave * a.tpw;
   const int ntab = t0 < a.T ? (int)(a.T - t0 < a.tpw ? a.T - t0 : a.tpw) : 0;
   uint4 Rnext = make_uint4(0, 0, 0, 0);
   if (ntab > 0 && lane < DDZ_NFIELDS) Rnext = ((const uint4*)(a.state + t0 * STATE_ROW_BYTES))[lane];
-  hot_fill<TB>(hot);
+  hot_fill<RW * 64>(hot);
   __syncthreads();
   uint64_t* stage = s_stage[wv];
   uint16_t* svl = s_svl[wv];
@@ -2443,6 +2445,7 @@ struct ddz_env {
   uint32_t auto_next; // next slot of the k_auto2 queue ring
   int slab_lpt;       // k_slab: block work list of deals + lists, heaviest first (tpw >= 2)
   int auto_teams;     // k_auto2: waves without tables help the searches of their block
+  int rollout_waves;  // k_rollout without ids / records: wavefronts per block (12: two blocks per CU; 16: one) -- ddz_debug_set_geometry
 };
 
 namespace {
@@ -2650,6 +2653,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
   e->slab_lpt = e->tpw >= 2;
+  e->rollout_waves = 12;
   e->auto_teams = 2;   // teams at the queue's end (1 = also team-first for the predicted-heaviest: measured, no gain -- DESIGN.md 9)
   *out = e;
   return DDZ_OK;
@@ -2916,12 +2920,25 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
   a.it_rows = it_rows; a.it_counts = it_counts;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
   const dim3 grid((unsigned)e->nblocks), block(TB);
+  // the variants without ids and trajectory records fit 85 VGPRs: 12-wave blocks, two per CU, tables per wave so that the grid
+  // is one round of 6 waves per SIMD (256 CUs x 24 waves)
+  constexpr int RW12 = 12;
+  const int tpw12 = (int)((e->T + 6143) / 6144 < 1 ? 1 : (e->T + 6143) / 6144);
+  const int64_t waves12 = (e->T + tpw12 - 1) / tpw12;
+  // ... when that grid fills the chip (>= 88 % of the 512 block slots: at 4096 tables a third of the CUs would hold two
+  // blocks and the others one -- measured 2.66 against 3.47 G steps/s; at 65,536 tables 3.98 against 3.59 G)
+  const bool dense = !ids && !traj && e->rollout_waves == RW12 && waves12 >= 5400;
+  const dim3 grid12((unsigned)((waves12 + RW12 - 1) / RW12)), block12(RW12 * 64);
+  if (dense) a.tpw = tpw12;
   // the kernel counts iterations and plies in 32 bits: at most 2^20 iterations per launch (about a second)
   constexpr int64_t CHUNK = 1 << 20;
   for (int64_t done = 0; done < n_iters; done += CHUNK) {
     a.n_iters = n_iters - done < CHUNK ? n_iters - done : CHUNK;
     a.traj = traj ? (uint4*)(traj + done * e->T * DDZ_TRAJ_BYTES) : nullptr;
-    if (it_rows) {
+    if (dense) {
+      if (it_rows) hipLaunchKernelGGL((k_rollout<false, false, true, RW12>), grid12, block12, 0, st, a);
+      else hipLaunchKernelGGL((k_rollout<false, false, false, RW12>), grid12, block12, 0, st, a);
+    } else if (it_rows) {
       if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true, true>), grid, block, 0, st, a);
       else if (ids) hipLaunchKernelGGL((k_rollout<true, false, true>), grid, block, 0, st, a);
       else if (traj) hipLaunchKernelGGL((k_rollout<false, true, true>), grid, block, 0, st, a);
@@ -3110,6 +3127,7 @@ int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int
     e->nblocks = (e->T + (int64_t)WPB * e->tpw - 1) / ((int64_t)WPB * e->tpw);
     e->counts_valid = false;  // the scan buffers depend on the geometry
     e->slab_lpt = e->tpw >= 2;
+    e->rollout_waves = WPB;   // (an explicit geometry also holds for the rollout: 16-wave blocks, this many tables per wave)
   }
   e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
   if (slab_work_list >= 0) e->slab_lpt = slab_work_list && e->tpw >= 2;
