@@ -2920,14 +2920,14 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
   a.it_rows = it_rows; a.it_counts = it_counts;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status; a.legal_rows = e->sc.legal_rows;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-  // the variants without ids and trajectory records fit 85 VGPRs: 12-wave blocks, two per CU, tables per wave so that the grid
+  // the variants without ids fit 85 VGPRs: 12-wave blocks, two per CU, tables per wave so that the grid
   // is one round of 6 waves per SIMD (256 CUs x 24 waves)
   constexpr int RW12 = 12;
   const int tpw12 = (int)((e->T + 6143) / 6144 < 1 ? 1 : (e->T + 6143) / 6144);
   const int64_t waves12 = (e->T + tpw12 - 1) / tpw12;
   // ... when that grid fills the chip (>= 88 % of the 512 block slots: at 4096 tables a third of the CUs would hold two
   // blocks and the others one -- measured 2.66 against 3.47 G steps/s; at 65,536 tables 3.98 against 3.59 G)
-  const bool dense = !ids && !traj && e->rollout_waves == RW12 && waves12 >= 5400;
+  const bool dense = !ids && e->rollout_waves == RW12 && waves12 >= 5400;   // (with records: 80 VGPRs + two spilled dwords)
   const dim3 grid12((unsigned)((waves12 + RW12 - 1) / RW12)), block12(RW12 * 64);
   if (dense) a.tpw = tpw12;
   // the kernel counts iterations and plies in 32 bits: at most 2^20 iterations per launch (about a second)
@@ -2936,7 +2936,9 @@ static int launch_rollout(ddz_env* e, int64_t n_iters, int32_t* counts, int8_t* 
     a.n_iters = n_iters - done < CHUNK ? n_iters - done : CHUNK;
     a.traj = traj ? (uint4*)(traj + done * e->T * DDZ_TRAJ_BYTES) : nullptr;
     if (dense) {
-      if (it_rows) hipLaunchKernelGGL((k_rollout<false, false, true, RW12>), grid12, block12, 0, st, a);
+      if (it_rows && traj) hipLaunchKernelGGL((k_rollout<false, true, true, RW12>), grid12, block12, 0, st, a);
+      else if (it_rows) hipLaunchKernelGGL((k_rollout<false, false, true, RW12>), grid12, block12, 0, st, a);
+      else if (traj) hipLaunchKernelGGL((k_rollout<false, true, false, RW12>), grid12, block12, 0, st, a);
       else hipLaunchKernelGGL((k_rollout<false, false, false, RW12>), grid12, block12, 0, st, a);
     } else if (it_rows) {
       if (ids && traj) hipLaunchKernelGGL((k_rollout<true, true, true>), grid, block, 0, st, a);

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void k_q_need_assign(const uint64_t* __restric
 // the `face` value broadcast by op_sel, no moves, bit-identical results -- measured SLOWER: 524 against 481 us at 65,536 tables
 // (190 VGPRs: two waves per SIMD instead of four, and the packed instruction does not issue faster than two plain ones).)
 template <int P>
-__global__ __launch_bounds__(QH) void k_q_feat_needed(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
+__global__ __launch_bounds__(QH) void k_q_feat_needed(   // ((QH, 5): 96 VGPRs + three spilled dwords, five waves per SIMD -- 536 against 466 us)
+    const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                       const float* __restrict__ bias, const float* __restrict__ acnt,
                                                       float* __restrict__ y0, float* __restrict__ dy, int64_t dy_rows,
                                                       const int32_t* __restrict__ pidx) {
