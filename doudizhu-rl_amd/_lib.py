@@ -40,6 +40,7 @@ SYMBOLS = {
     "ddz_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ddz_state_prob": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_rows_to_onehot": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ddz_observe_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ddz_get_moves": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddz_get_moves_slab": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -23,13 +23,26 @@
 // Included by ddz_engine.hip after ddz_auto.h.
 #pragma once
 
+// geometry (the -D overrides are tools/auto_occupancy_probe.py's: experiments, not product builds)
+#ifndef DDZ_A2_WPB
+#define DDZ_A2_WPB 8
+#endif
+#ifndef DDZ_A2_CAP
+#define DDZ_A2_CAP 96
+#endif
+#ifndef DDZ_A2_BOX
+#define DDZ_A2_BOX 128
+#endif
+#ifndef DDZ_A2_OCC
+#define DDZ_A2_OCC 2
+#endif
 constexpr int A2_CAND = STAGE_CAP;  // candidates per table: the proven maximum of a <= 20-card hand
-constexpr int A2_WPB = 8;         // waves per block (17 KB of LDS per wave + the shared record table + the team: 156 KB)
+constexpr int A2_WPB = DDZ_A2_WPB;  // waves per block (17 KB of LDS per wave + the shared record table + the team: 156 KB)
 constexpr int A2_TB = A2_WPB * 64;
-constexpr int A2_CAP = 96;        // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
+constexpr int A2_CAP = DDZ_A2_CAP;  // frontier items per table (>= 64: the spare buffer is the mailbox of the donations)
 constexpr int A2_KEYLEVELS = 7;   // order keys: 9-bit digits (child position + 1) of the first seven levels of the path
 constexpr int A2_PASSES = 6;      // expansion passes at most
-constexpr int A2_TARGET = 64;     // ... or until the list feeds 64 lanes
+constexpr int A2_TARGET = 64;     // ... or until the list feeds 64 lanes (the take / mailbox code is written for exactly one item per lane)
 constexpr int A2_DEPTH = 20;      // actions below an item's root (a combination has at most 20 actions)
 constexpr int A2_NOFROM = 1023;
 constexpr int A2_TICKET_SLOTS = 1024;  // ring of per-launch ticket words (ddz_engine.hip launch_auto)
@@ -54,7 +67,7 @@ struct Auto2Wave {              // per wave
   uint16_t bstart[16];
 };
 
-constexpr int A2_BOX = 128;       // items the team's box holds
+constexpr int A2_BOX = DDZ_A2_BOX; // items the team's box holds
 // A search shared by the waves of a block (k_auto2 "teams"; one per block at a time -- a launch of 65,536 tables opens
 // about ten): the decision of wave `owner`, opened to the block's waves that found the queue empty.  Everything but the
 // peeks at `open`, `hungry`, `box_n`, `active` and `thr` is read and written under `lock`.
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(AO_BT) void k_auto_order(const uint8_t* __restrict_
 #define A2DBG(k, v) do { } while (0)
 #endif
 template <bool STATE>
-__global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
+__global__ __launch_bounds__(A2_TB, DDZ_A2_OCC) void k_auto2(AutoArgs a) {
   __shared__ HotTabT<false> hot;
   __shared__ Auto2Wave s_w[A2_WPB];
   __shared__ A2Team s_team;
@@ -972,7 +985,7 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
           A2DBG(8, n_act); A2DBG(9, n_none); A2DBG(10, n_pend); A2DBG(11, n_key); A2DBG(12, __popcll(donors_t));
         }
 #endif
-        if (!in_team && donors_t && (a2_peek(&s_drained) != 0 || first_owner) && !a2_peek(&TM.open)) {
+        if (!in_team && (donors_t || (first_owner && trip == 0)) && (a2_peek(&s_drained) != 0 || first_owner) && !a2_peek(&TM.open)) {
           // the owner opens the team: waves of the block have run out of queue, this search has lasted a while and has
           // subtrees to give (and no other search of the block is being shared)
           a2_lock(&TM.lock, lane, a.status);
@@ -983,6 +996,18 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             a2_thr_store(TM, thr); TM.hand = q.hand; TM.bsw0 = bsw0; TM.bsw1 = bsw1; TM.bsw2 = bsw2; TM.sm0 = sm0; TM.sm1 = sm1;
             TM.rp = q.rp; TM.esingle = q.esingle; TM.epair = q.epair;
             TM.open = 1;
+          }
+          if (mine && first_owner && trip == 0 && next_item > 8) {
+            // a team from the start: the frontier goes to the box, the owner keeps an eighth of it
+            int nb = next_item - (next_item + 7) / 8;
+            if (nb > A2_BOX) nb = A2_BOX;
+            const int s0 = next_item - nb;
+            for (int i = lane; i < nb; i += 64) {
+              TM.bA[i] = W.itA[cur][s0 + i]; TM.bB[i] = W.itB[cur][s0 + i]; TM.bM[i] = W.itM[cur][s0 + i];
+              TM.bI[i] = W.itI[cur][s0 + i]; TM.bK[i] = W.itK[cur][s0 + i];
+            }
+            if (lane == 0) TM.box_n = (uint32_t)nb;
+            next_item = s0;
           }
           a2_unlock(&TM.lock, lane);
           in_team = mine;
@@ -1024,7 +1049,9 @@ __global__ __launch_bounds__(A2_TB, 2) void k_auto2(AutoArgs a) {
             a2_lock(&TM.lock, lane, a.status);
             const int bn = (int)rfl(TM.box_n);
             const bool over = bn == 0 && (int)rfl(TM.active) == (waiting ? 0 : 1);
-            const int nt = bn < 64 ? bn : 64, b0 = bn - nt;  // the last items put (one per lane at most)
+            int nt = (bn + 7) >> 3;                          // a share of the box: other members wait there too
+            nt = nt < 4 ? 4 : nt; nt = nt > 64 ? 64 : nt; nt = nt > bn ? bn : nt;
+            const int b0 = bn - nt;                          // the last items put (one per lane at most)
             if (lane < nt) {
               W.itA[cur][lane] = TM.bA[b0 + lane]; W.itB[cur][lane] = TM.bB[b0 + lane]; W.itM[cur][lane] = TM.bM[b0 + lane];
               W.itI[cur][lane] = TM.bI[b0 + lane]; W.itK[cur][lane] = TM.bK[b0 + lane];

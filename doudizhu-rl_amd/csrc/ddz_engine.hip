@@ -127,7 +127,10 @@ constexpr int EM_SLAB = 5;    // rows (+ids) built from nib | category straight 
                               // (no record rows in LDS, no staging list, no flush pass: what k_slab's list phase uses)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
-constexpr int STAGE_CAP = 500;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
+#ifndef DDZ_STAGE_CAP
+#define DDZ_STAGE_CAP 500
+#endif
+constexpr int STAGE_CAP = DDZ_STAGE_CAP;  // >= the largest list of a <=20-card hand: 497, PROVEN by exhaustive enumeration (tools/max_legal_bound.c, tests/test_rules_bounds.py);
                                  // 500 keeps k_rollout's block at 53 KB of LDS = three blocks per CU
 // the row with list index `want` is captured (wave-uniform) while it is emitted
 struct Pick {
@@ -2827,6 +2830,14 @@ int ddz_rows_to_onehot(int device, const int8_t* rows, int64_t n, float* out, vo
   hipLaunchKernelGGL(k_onehot, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)rows, n, (float4*)out);
   return check_launch();
+}
+
+int ddz_observe_actions(ddz_env_t* e, int variant, float* face, const int8_t* rows, int64_t n, float* onehot, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (n < 0 || (n > 0 && (!rows || !onehot)) || !al(rows, 16) || !al(onehot, 16)) return DDZ_EINVAL;
+  const int rc = ddz_observe(e, variant, face, stream);
+  if (rc != DDZ_OK || n == 0) return rc;
+  return ddz_rows_to_onehot(e->device, rows, n, onehot, stream);
 }
 
 int ddz_state_prob(int device, const uint8_t* known60, const int32_t* sizes, int64_t n, float* out, void* stream) {

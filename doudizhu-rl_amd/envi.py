@@ -20,6 +20,23 @@ from .engine import (BatchedEnv, F_HAND0, F_HIST0, F_META, F_RECENT0, F_TAKEN, S
                      rows_to_onehot, state_prob)
 
 
+class _OldCards(dict):
+    """Env.old_cards (envi.py:27,65: the actor's hand before its move, as cards 3..17 -- read by the debug print only,
+    envi.py:46): kept as the 15 rank counts of the state row, turned into the reference's card array when read."""
+
+    def __getitem__(self, role):
+        return Env.arr2cards(dict.__getitem__(self, role))
+
+    def get(self, role, default=None):
+        return self[role] if role in self else default
+
+    def values(self):
+        return [self[k] for k in self]
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+
 class Env:
     FACE_VARIANT = 0  # envi.py:87-96: [hand, taken, prob1, prob2]
 
@@ -34,11 +51,15 @@ class Env:
         self._sel = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._row = torch.zeros((1, 16), dtype=torch.int8).pin_memory()
         self._ids = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._sel_np, self._row_np = self._sel.numpy(), self._row.numpy()   # (a numpy store costs 0.1 us, a tensor store 1.5)
         self._s = self._b.state.numpy().reshape(11, 16)          # live view of the state rows
         self._n = self._b.counts.numpy()                          # ... and of the size of the legal list
+        self._m = self._s[F_META]                                 # the meta row (a view: always current)
+        self._ply16 = self._m[4:6].view(np.uint16)                # its ply counter
         self._nlegal = 0
+        self._views = None
         self.debug = debug
-        self.old_cards = dict()
+        self.old_cards = _OldCards()
         # lean call paths of the three per-ply calls (face / valid_actions / step): the library functions bound once, the
         # persistent buffers' pointers converted once (the generic BatchedEnv wrappers spend ~10 us per call on checks)
         import ctypes as C
@@ -77,7 +98,7 @@ class Env:
         return self._s[F_HAND0:F_HAND0 + 3, :15]
 
     def _clear(self):
-        self.old_cards = dict()
+        self.old_cards = _OldCards()
 
     def _sync(self):
         rc = self._L.ddz_sync(self._di, self._C.c_void_p(self._raw(self._di)))   # the one wait of a ply
@@ -85,6 +106,22 @@ class Env:
             from ._lib import check
             check(rc)
         self._nlegal = int(self._n[0])
+        self._views = None
+
+    def _observe_actions(self):
+        """`face` and valid_actions() of the current state from ONE allocation and ONE library call (ddz_observe_actions:
+        the launches of ddz_observe and ddz_rows_to_onehot): what an agent reads per ply (dqn.py:50-71).  Each of the two
+        tensors is handed out once; a second read of the same property in the same ply computes a fresh one."""
+        n, P = self._nlegal, self._P
+        buf = torch.empty(((P + n) * 60,), dtype=torch.float32, device=self.device)
+        p0 = buf.data_ptr()
+        rc = self._L.ddz_observe_actions(self._h, self.FACE_VARIANT, self._C.c_void_p(p0), self._C.c_void_p(self._rows_ptr), n,
+                                         self._C.c_void_p(p0 + P * 240), self._C.c_void_p(self._raw(self._di)))
+        if rc:
+            from ._lib import check
+            check(rc)
+        v = self._views = [buf[:P * 60].view(P, 15, 4), buf[P * 60:].view(n, 15, 4)]
+        return v
 
     def reset(self):
         """envi.py:30-36: clears the adapter state; cards are dealt by prepare()."""
@@ -128,14 +165,15 @@ class Env:
 
     # ---- stepping ----
     def _ply(self):
-        return int(self._meta[4]) | (int(self._meta[5]) << 8)
+        return int(self._ply16[0])
 
     def _step(self, sel, mode):
         """one launch (apply + the next state's legal list) + ONE device -> host round trip (_sync): done / r are the
         meta row's, an action that was not in the legal list leaves the table untouched (same ply counter)"""
-        if self._meta[1]:  # a finished table stays as it is (no auto-reset in this view)
+        m = self._m
+        if m[1]:  # a finished table stays as it is (no auto-reset in this view)
             return 0, True
-        before = self._ply()
+        before = int(self._ply16[0])
         b, pp = self._b, self._pp
         if not b._slab_fresh:
             b.legal_slab()
@@ -147,15 +185,15 @@ class Env:
             check(rc)
         b._legal_fresh, b._slab_fresh, b._csr_fresh = False, True, False    # (as BatchedEnv.step_slab)
         self._sync()
-        if self._ply() == before:
+        if int(self._ply16[0]) == before:
             raise ValueError("illegal action for the current state")
-        r = int(self._meta[3])
-        return (r - 256 if r > 127 else r), bool(self._meta[1])
+        r = int(m[3])
+        return (r - 256 if r > 127 else r), bool(m[1])
 
     def _apply(self, idx):
-        role = self.get_role_ID() - 1
-        self.old_cards[role] = self.get_curr_handcards()
-        self._sel[0] = int(idx)
+        role = int(self._m[0])
+        self.old_cards[role] = self._s[F_HAND0 + role, :15].copy()
+        self._sel_np[0] = idx
         r, done = self._step(self._sel, STEP_CHOICE)
         res = (r, done, None)
         if self.debug:
@@ -166,9 +204,9 @@ class Env:
     def step_manual(self, onehot_cards):
         """envi.py:63-70: 15x4 thermometer -> (r, done, _); r -1 lord wins / +1 farmers.  The engine checks the cards
         against the legal list itself (DDZ_STEP_ROWS)."""
-        role = self.get_role_ID() - 1
-        self.old_cards[role] = self.get_curr_handcards()
-        self._row[0, :15] = torch.from_numpy(np.asarray(self.onehot2arr(onehot_cards), dtype=np.int8))
+        role = int(self._m[0])
+        self.old_cards[role] = self._s[F_HAND0 + role, :15].copy()
+        self._row_np[0, :15] = self.onehot2arr(onehot_cards)
         r, done = self._step(self._row, STEP_ROWS)
         if self.debug:
             print('role {} plays {}, left {}'.format(
@@ -179,8 +217,8 @@ class Env:
         """envi.py:72-77: the rule-based opponent moves -> (cards, r, _).  The native step_auto is absent from the
         reference; this plays RuleBasedModel.choose (rule_based/utils/rule_based_model.py:43-101) on the device
         (decomposer spec v1)."""
-        role = self.get_role_ID() - 1
-        self.old_cards[role] = self.get_curr_handcards()
+        role = int(self._m[0])
+        self.old_cards[role] = self._s[F_HAND0 + role, :15].copy()
         ids = self._b.auto_choose(0b111, out=self._ids)   # (the id lands in pinned memory; the step reads it from there)
         r, _ = self._step(ids, STEP_IDS)  # (an id the rule agent could not produce -- DDZ_AUTO_INVALID -- raises here)
         cards = self.arr2cards(self.recent_handout[role].astype(int))
@@ -198,6 +236,12 @@ class Env:
     # ---- observations ----
     @property
     def face(self):
+        v = self._views
+        if v is None:
+            v = self._observe_actions()
+        if v[0] is not None:
+            out, v[0] = v[0], None
+            return out
         out = torch.empty((self._P, 15, 4), dtype=torch.float32, device=self.device)
         rc = self._L.ddz_observe(self._h, self.FACE_VARIANT, self._C.c_void_p(out.data_ptr()), self._C.c_void_p(self._raw(self._di)))
         if rc:
@@ -209,6 +253,12 @@ class Env:
         """envi.py:98-116: f32 [A,15,4] on the device, or a list of A int[15] arrays."""
         rows, n = self._legal()
         if tensor:
+            v = self._views
+            if v is None:
+                v = self._observe_actions()
+            if v[1] is not None:
+                out, v[1] = v[1], None
+                return out
             out = torch.empty((n, 15, 4), dtype=torch.float32, device=self.device)
             if n:
                 rc = self._L.ddz_rows_to_onehot(self._di, self._C.c_void_p(self._rows_ptr), n, self._C.c_void_p(out.data_ptr()),

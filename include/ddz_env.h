@@ -159,6 +159,11 @@ int ddz_slab_to_csr(ddz_env_t* env, const int32_t* counts, const int8_t* rows, c
 /* Replaces the `face` property of the four Env classes: f32 [T][P][15][4].            */
 int ddz_observe(ddz_env_t* env, int variant, float* face, void* stream);
 
+/* What an agent reads per ply -- `face` (envi.py:87-96,165-217) and valid_actions(tensor=True) (envi.py:98-116) -- in ONE
+ * call: ddz_observe(env, variant, face) followed by ddz_rows_to_onehot(rows, n, onehot) on the same stream (n = 0: the
+ * face only).  The N = 1 `Env` view's per-ply call; the two launches are the ones of the separate entry points.        */
+int ddz_observe_actions(ddz_env_t* env, int variant, float* face, const int8_t* rows, int64_t n, float* onehot, void* stream);
+
 /* Replaces the native get_state_prob_manual(known60, size1, size2) (server/core.py:26-33; Env.get_state_prob(),
  * envi.py:94, is the same function of the live table): known60 u8[n][60] = thermometer of the cards the actor can see
  * (own hand + everything played), sizes int32[n][2] = cards left of the next and the next-but-one player;

@@ -587,7 +587,15 @@ def test_env_view_matches_reference_api(pkg, oracle):
     _, _, rids = ref.legal()
     lst = env.valid_actions(tensor=False)
     assert len(lst) == len(rids) == acts.shape[0]
+    # face + valid_actions come from one library call per ply (ddz_observe_actions); reading a property again in the same
+    # ply gives a fresh, equal tensor -- never the one handed out before
+    face2, acts2 = env.face, env.valid_actions()
+    assert face2.data_ptr() != face.data_ptr() and torch.equal(face2, face)
+    assert acts2.data_ptr() != acts.data_ptr() and torch.equal(acts2, acts)
+    assert np.array_equal(acts.cpu().numpy().sum(-1).astype(int), np.stack(lst))
+    hand_before = env.get_curr_handcards()
     r, done, _ = env.step_manual(acts[-1])
+    assert np.array_equal(env.old_cards[1], hand_before) and list(env.old_cards.items())[0][0] == 1   # envi.py:65
     assert (r, done) == (0, False) and env.get_role_ID() == 3                  # down moves next
     assert env.taken.sum() == 20 - env.left[1] and env.history[1].sum() == env.taken.sum()
     # get_last_outcards(): what `down` has to beat = the lord's play as ranks 3..17 (envi.py:103-109; the `last_cards`

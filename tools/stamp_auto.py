@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 csrc = os.path.join(ROOT, "doudizhu-rl_amd", "csrc")
 out = os.path.join(ROOT, "build_variants")
 os.makedirs(out, exist_ok=True)
@@ -23,9 +24,14 @@ raw.ddz_debug_set_stamps.argtypes = [C.c_void_p]
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 env = pkg.BatchedEnv(T, seed=0)
 env.reset()
-env.legal_slab()
-for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):   # mid-game states of rule farmers against a random lord
-    env.step_auto(0b101, slab=True)
+if os.environ.get("DDZ_STAMP_HEAVY"):   # the heaviest states of fixture G8h on the first N tables instead (tools/team_probe.py)
+    from team_probe import heavy_states
+    st_, _, _ = heavy_states(pkg, T, int(os.environ["DDZ_STAMP_HEAVY"]))
+    env.state_import(torch.from_numpy(st_).view(-1))
+else:
+    env.legal_slab()
+    for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):   # mid-game states of rule farmers against a random lord
+        env.step_auto(0b101, slab=True)
 if len(sys.argv) > 4:  # teams off
     env.lib.ddz_debug_set_auto_teams(env._h, int(sys.argv[4]))
 ROLES = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0b111
@@ -85,7 +91,8 @@ for w in range(0, nw, 37):
     idx = np.nonzero(wave == w)[0]
     idx = idx[np.argsort(t_start[idx])]
     gaps += list(t_start[idx][1:] - t_end[idx][:-1])
-print(f"  gap between a wave's decisions (ticket + order + state loads): mean {np.mean(gaps):.0f} p90 {np.percentile(gaps, 90):.0f} cycles")
+if gaps:
+    print(f"  gap between a wave's decisions (ticket + order + state loads): mean {np.mean(gaps):.0f} p90 {np.percentile(gaps, 90):.0f} cycles")
 heavy = np.argsort(-tot)[:5]
 for h in heavy:
     print("   heavy:", [int(x) for x in s[h, :8]])
