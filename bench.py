@@ -199,9 +199,11 @@ def rollout_leg(pkg, torch, dev, T, pmc_key):
                                  env_steps_per_launch=steps / n, algorithmic_bytes_per_env_step=260 + 16 * mean_a,
                                  issue=issue_block(pmc_key, steps / n, dur))}
     env.rollout_random_csr(64)
-    dtc, repc = timed_loop(lambda: env.rollout_random_csr(256), sync)
-    out["csr_env_steps_per_s"] = T * 256 * repc / dtc
-    out["csr_us_per_iteration"] = dtc / (256 * repc) * 1e6
+    nc = 1024 if T <= 8192 else 256
+    dtc, repc = timed_loop(lambda: env.rollout_random_csr(nc), sync)
+    out["csr_env_steps_per_s"] = T * nc * repc / dtc
+    out["csr_us_per_iteration"] = dtc / (nc * repc) * 1e6
+    out["csr_staging_GiB"] = env._staging.numel() / 2**30
     env.rollout_random_csr(20, batch=0)
     dtc, repc = timed_loop(lambda: env.rollout_random_csr(50, batch=0), sync)
     out["csr_launch_per_iteration_env_steps_per_s"] = T * 50 * repc / dtc
@@ -716,6 +718,7 @@ def main():
                        "mean_legal_moves": round(mean_a, 3), "episodes": st["episodes"],
                        "list_layout": "slab (fixed-stride segment per table)",
                        "csr_env_steps_per_s": csr_rate, "csr_us_per_iteration": csr_us,
+                       "csr_staging_GiB": env._staging.numel() / 2**30,
                        "csr_launch_per_iteration_env_steps_per_s": csr_rate_per_launch,
                        "csr_note": "the same loop with packed CSR lists (offsets / rows as ddz_legal writes them: SURVEY 8(d) "
                                    "config 2 'outputs = CSR legal list only') beside the slab layout of `value`: batches of "

@@ -22,6 +22,7 @@ F_HAND0, F_HIST0, F_RECENT0, F_TAKEN, F_META = 0, 3, 6, 9, 10
 # a 20-card hand never has more than this many legal moves (tests/test_rules_bounds.py);
 # the default row capacity is T * MAX_LEGAL_PER_TABLE so the CSR list cannot overflow.
 MAX_LEGAL_PER_TABLE = 512
+CSR_STAGING_BYTES = 16 << 30  # default staging budget of rollout_random_csr (slabs of a batch of iterations)
 
 
 def _require_gpu(device):
@@ -495,16 +496,18 @@ class BatchedEnv:
     def rollout_random_csr(self, n_iters, traj=None, batch=None):
         """The same loop with packed CSR lists (offsets/rows/ids as legal() returns them: afterwards they hold the lists
         of the last iteration's pre-step states).  Same states and trajectories as rollout_random.
-        batch (default: as many iterations as ~2 GiB of staging hold, at most 32): the lists of a batch of iterations are
-        staged as slabs by ONE rollout launch and compacted to CSR by two more (ddz_rollout_random_csr_staged) -- no launch
-        per iteration; batch=0: the one-launch-per-iteration form (ddz_rollout_random_csr: CSR bases depend on every
-        table, so each iteration waits for the scan of the one before)."""
+        batch (default: as many iterations as CSR_STAGING_BYTES = 16 GiB of staging hold -- 32 at 65,536 tables, 512 at 4096;
+        the device has 288 GB -- at most 512): the lists of a batch of iterations are staged as slabs by ONE rollout launch and
+        compacted to CSR by two more (ddz_rollout_random_csr_staged) -- no launch per iteration, and the longer the batch the
+        less the launch's prologue weighs (tools/csr_batch_probe.py: 65,536 tables 1.95 G steps/s at 4 iterations per batch,
+        2.81 G at 32); batch=0: the one-launch-per-iteration form (ddz_rollout_random_csr: CSR bases depend on every table,
+        so each iteration waits for the scan of the one before)."""
         if traj is not None and (traj.dtype != torch.uint8 or not traj.is_contiguous()
                                  or traj.numel() != n_iters * self.T * TRAJ_BYTES):
             raise ValueError("traj must be a contiguous uint8 [n_iters,T,32] tensor")
         if batch is None:
             per = self.T * MAX_LEGAL_PER_TABLE * (20 if self.ids is not None else 16)
-            batch = max(2, min(32, (2 << 30) // per))
+            batch = max(2, min(512, CSR_STAGING_BYTES // per))
         if batch:
             batch = int(min(batch, max(1, n_iters)))
             need = self.lib.ddz_rollout_csr_staging_bytes(self.T, batch, int(self.ids is not None))

@@ -975,6 +975,7 @@ def test_bench_contract():
     assert r["launches_timed"] >= 2 and r["launch_us"] * r["launches_timed"] >= 45e3
     # the CSR layout beside the slab layout, at the same table count
     assert j["config"]["csr_env_steps_per_s"] > 1e8 and j["config"]["csr_launch_per_iteration_env_steps_per_s"] > 1e7
+    assert 0 < j["config"]["csr_staging_GiB"] <= 17   # the staged CSR rollout's slabs (engine.CSR_STAGING_BYTES)
     assert j["config"]["per_rank_env_steps_per_s"] == [j["value"]]
     iss = r["issue"]
     assert iss is None or (iss["bound"] == "valu-issue" and 0 < iss["frac"] < 1 and "profiles/" in " ".join(iss["sources"].values())
