@@ -125,6 +125,14 @@ constexpr int EM_STAGE = 3;   // nib + category (+id) into the wave's LDS stagin
 constexpr int EM_MASK = 4;    // bit `id` of the wave's LDS mask (get_mask, utils.py:45-63)
 constexpr int EM_SLAB = 5;    // rows (+ids) built from nib | category straight into the table's slab at base + running index
                               // (no record rows in LDS, no staging list, no flush pass: what k_slab's list phase uses)
+// One list written by ALL the waves of a block (k_slab with one table per wave: such a launch waits for its slowest list,
+// the lord's 20-card lead of a fresh game).  The plan of a list is wave-uniform SCALAR work -- sixteen waves repeating it
+// would queue on the CU's one scalar unit -- so the table's own wave runs it once in this mode, leaving one 8-byte record per
+// scan round (64 candidate ids) in LDS; the rounds are then executed from the records (team_round): by the wave itself when
+// they are few, otherwise dealt out over the block's waves -- counted, scanned, written at their bases: byte for byte the
+// list EM_SLAB writes (ascending canonical id).
+constexpr int EM_TEAM_PLAN = 6;
+constexpr int TEAM_ROUNDS = 256;  // >= the scan rounds of any lead of a <= 20-card hand (at most ~210: see team_round)
 [[maybe_unused]] constexpr int ID_JK_FOUR = DDZ_NUM_ACTIONS;        // quad q + both jokers: ids 13527 + q
 [[maybe_unused]] constexpr int ID_JK_PLANE = DDZ_NUM_ACTIONS + 13;  // triples s, s+1 + both jokers: ids 13540 + s
 #ifndef DDZ_STAGE_CAP
@@ -136,6 +144,9 @@ constexpr int STAGE_CAP = DDZ_STAGE_CAP;  // >= the largest list of a <=20-card 
 struct Pick {
   int want;
   uint32_t r0, r1, r2, r3;
+  // EM_TEAM_PLAN: the number of rounds so far, their records in LDS
+  int rc = 0;
+  uint2* desc = nullptr;
 };
 
 #include "ddz_build_table.h"
@@ -161,6 +172,7 @@ constexpr int CL_N[9] = {91, 78, 66, 55, 220, 120, 330, 126, 252};
 constexpr int CL_OFF[10] = {0, 91, 169, 235, 290, 510, 630, 960, 1086, 1338};
 constexpr int COMBO_WORDS = 1338;
 __device__ uint32_t g_combo[COMBO_WORDS];
+__device__ uint64_t g_c64[COMBO_WORDS];  // the same combinations as nibble sets over the remains list (1 per kicker): team_round
 // the 16-byte row (counts + category) of a canonical action id, including the joker-kicker extras of that build
 __device__ __forceinline__ uint4 row_of_id(int id) {
   if (id < DDZ_NUM_ACTIONS) return g_tab[2 * id];
@@ -179,8 +191,10 @@ __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
     int idx[5] = {0, 1, 2, 3, 4};
     for (int e = 0; e < CL_N[lane]; ++e) {
       uint32_t w = 0;
-      for (int k = 0; k < L; ++k) w |= (uint32_t)idx[k] << (4 * k);
+      uint64_t c = 0;
+      for (int k = 0; k < L; ++k) { w |= (uint32_t)idx[k] << (4 * k); c += 1ull << (4 * idx[k]); }
       g_combo[CL_OFF[lane] + e] = w;
+      g_c64[CL_OFF[lane] + e] = c;
       int i = L - 1;
       while (i >= 0 && idx[i] == R - L + i) --i;
       if (i >= 0) {
@@ -235,6 +249,11 @@ __device__ __forceinline__ uint4 sel4(bool c, const uint4& a, const uint4& b) {
   return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
+// EM_TEAM_PLAN's record of a scan round: x = candidates - 1 (6 bits) | first id << 6 (14) | first hot slot / combination
+// word << 20 (11); y = kind (0 hot ids, 1 kicker block, 2 the joker-kicker extras) | the block's shape
+__device__ __forceinline__ uint32_t team_x(int left, int id, int so) {
+  return (uint32_t)((left < 64 ? left : 64) - 1) | (uint32_t)id << 6 | (uint32_t)so << 20;
+}
 // the action a lane is looking at, however its record was obtained
 template <int EM, bool IDS>
 __device__ __forceinline__ int scan_emit(bool legal, int id, uint64_t nib, int cat, int vl, uint4 row, const Out& o,
@@ -288,6 +307,12 @@ __device__ __forceinline__ int scan_ids(int id0, int count, const HT& hot, uint6
   constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
   constexpr uint64_t H8 = 0x8888888888888888ull;
   const int slot0 = id0 == ID_BIGBANG ? HOT_IDS : id0;
+  if (EM == EM_TEAM_PLAN) {  // (leads only: no follow gate) record: ids id0 + j0 ..., their hot slots
+    for (int j0 = 0; j0 < count; j0 += 64, ++pk.rc)
+      if (pk.rc < TEAM_ROUNDS)
+        pk.desc[pk.rc] = make_uint2(team_x(count - j0, id0 + j0, slot0 + j0), 0u);
+    return n;
+  }
   for (int j0 = 0; j0 < count; j0 += 64) {
     const int j = j0 + lane;
     const bool in = j < count;
@@ -316,6 +341,13 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
   constexpr bool ROWS = EM == EM_WRITE || EM == EM_PICK;
   constexpr uint64_t H8 = 0x8888888888888888ull;
   const int L = CL_L[list], off = CL_OFF[list];
+  if (EM == EM_TEAM_PLAN) {  // record: ids idb + j0 ..., combination words off + j0 ..., the block's shape
+    for (int j0 = 0; j0 < count; j0 += 64, ++pk.rc)
+      if (pk.rc < TEAM_ROUNDS)
+        pk.desc[pk.rc] = make_uint2(team_x(count - j0, idb + j0, off + j0),
+                                    1u | (uint32_t)L << 2 | (uint32_t)s << 5 | (uint32_t)gap << 9 | (uint32_t)mult << 12 | (uint32_t)cat << 14);
+    return n;
+  }
   for (int j0 = 0; j0 < count; j0 += 64) {
     const int j = j0 + lane;
     const bool in = j < count;
@@ -436,7 +468,12 @@ __device__ __forceinline__ int plan_scan_t(uint64_t hand, const Follow& f, const
     const uint32_t mm = m3 & M12;
     const uint32_t quads = (LEAD || f.lc == FOUR_TAKE_ONE) ? (m4 & above) : 0u;
     const uint32_t pairs3 = (LEAD || (f.lc == THREE_ONE_LINE && f.ll == 2)) ? (mm & (mm >> 1) & above) : 0u;
-    if (quads | pairs3) {
+    if (EM == EM_TEAM_PLAN) {
+      if (quads | pairs3) {
+        if (pk.rc < TEAM_ROUNDS) pk.desc[pk.rc] = make_uint2(team_x(24, ID_JK_FOUR, 0), 2u | quads << 2 | pairs3 << 15);
+        ++pk.rc;
+      }
+    } else if (quads | pairs3) {
       const bool isq = lane < 13;
       const int r = isq ? lane : (lane - 13) & 15;
       const bool ok = isq ? ((quads >> r) & 1u) : (lane < 24 && ((pairs3 >> r) & 1u));
@@ -484,16 +521,17 @@ __device__ __forceinline__ int plan_scan(uint64_t hand, uint32_t info, const HT&
 
 // every thread of the block copies its share of the hot records into LDS (callers issue
 // their own independent global loads first so that all of them are in flight together)
-template <int NT, class HT>
+// (OFF: the block's first OFF threads do not take part and do not call)
+template <int NT, class HT, int OFF = 0>
 __device__ __forceinline__ void hot_fill(HT& hot) {
 #pragma unroll
-  for (int i = threadIdx.x; i < HOT_SLOTS; i += NT) {
+  for (int i = (int)threadIdx.x - OFF; i < HOT_SLOTS; i += NT - OFF) {
     const int id = i < HOT_IDS ? i : ID_BIGBANG;
     hot.meta[i] = g_tab[2 * id + 1];
     if (HT::HAS_ROWS) hot.rows[i] = g_tab[2 * id];
   }
 #pragma unroll
-  for (int i = threadIdx.x; i < COMBO_WORDS; i += NT) hot.combo[i] = g_combo[i];
+  for (int i = (int)threadIdx.x - OFF; i < COMBO_WORDS; i += NT - OFF) hot.combo[i] = g_combo[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -517,6 +555,30 @@ __device__ inline void deal_wave(uint64_t gid, uint32_t episode, uint32_t k0, ui
   int pos = 0;
 #pragma unroll 6
   for (int j = 0; j < 54; ++j) pos += rl64(kk, j) < kk ? 1 : 0;
+  const bool card = lane < 54;
+  o0 = nib_from_cards(__ballot(card && pos < 17));
+  o1 = nib_from_cards(__ballot(card && pos >= 17 && pos < 37));
+  o2 = nib_from_cards(__ballot(card && pos >= 37));
+}
+
+// The same deal with the ranking through LDS: the 54 keys stored once, every lane reads them back two at a time (uniform
+// address: a broadcast) instead of 108 v_readlane -- a lone wave on its SIMD issues one of those per ~25 cycles (k_slab with
+// one table per wave, where a deal sits on the launch's critical path).  `keys`: 64 x 8 bytes of the calling wave.
+__device__ inline void deal_wave_lds(uint64_t gid, uint32_t episode, uint32_t k0, uint32_t k1, int lane, uint64_t* keys,
+                                     uint64_t& o0, uint64_t& o1, uint64_t& o2) {
+  const uint4 d = philox4x32_10(make_uint4((uint32_t)gid, (uint32_t)(gid >> 32), episode, (1u << 16) | (uint32_t)(lane >> 2)), k0, k1);
+  const int w = lane & 3;
+  const uint32_t key = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+  const uint64_t kk = ((uint64_t)key << 6) | (uint32_t)lane;
+  keys[lane] = kk;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int pos = 0;
+#pragma unroll 9
+  for (int j = 0; j < 54; j += 2) {
+    const ulonglong2 v = *(const ulonglong2*)&keys[j];
+    pos += (v.x < kk ? 1 : 0) + (v.y < kk ? 1 : 0);
+  }
   const bool card = lane < 54;
   o0 = nib_from_cards(__ballot(card && pos < 17));
   o1 = nib_from_cards(__ballot(card && pos >= 17 && pos < 37));
@@ -1172,6 +1234,7 @@ struct SlabArgs {
   float4* face;         // [T][P][15] `face` of the NEW states, or null
   int face_variant;
   int coop;             // tpw == 1: wave 0 of a block runs the lane-parallel phases of the block's tables
+  int team;             // coop: planned leads of at least this many scan rounds are written by the whole block (0 = none)
   int lpt;              // tpw >= 2: deals + lists of a block's tables go through a block work list, most expensive first
 };
 constexpr int STEP_Q = 4;  // internal mode of k_slab: sel = f32 q[T][stride]
@@ -1231,6 +1294,59 @@ __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t b
     }
   }
   return n;
+}
+
+// One scan round of a lead from its EM_TEAM_PLAN record: the lanes' candidates exactly as scan_ids / scan_combos build them
+// (legal <=> subset of the hand: a lead has no follow gate).  WRITE: the legal rows (+ ids) to rows[base + lanes below];
+// returns the number of legal candidates.
+// Rounds of a lead: ids 1..54 (1), 3+1 / 3+2 (<= 3 + 3), the chains (<= 3), one kicker block per (start, length) of a triple
+// run -- a <= 20-card hand holds <= 6 triples: <= 15 blocks of <= 6 rounds per plane category --, the rocket, <= 5 quads x
+// (2 + 2): ~210 at most, TEAM_ROUNDS = 256; a plan with more sets status bit 1 and writes an empty list.
+template <bool WRITE, bool IDS, class HT>
+__device__ __forceinline__ int team_round(uint2 d, uint64_t hand8, const HT& hot, const uint64_t* c64, int lane, int64_t base,
+                                          int64_t cap, uint4* rows, int32_t* ids) {
+  constexpr uint64_t H8 = 0x8888888888888888ull;
+  const uint32_t dx = rfl(d.x), dy = rfl(d.y);
+  const int nv = (int)(dx & 63u) + 1, id = (int)((dx >> 6) & 0x3FFFu) + lane, so = (int)(dx >> 20);
+  const bool in = lane < nv;
+  const uint32_t kind = dy & 3u;
+  uint64_t nib;
+  int cat;
+  bool ok = in;
+  if (kind == 0) {
+    const uint4 m = hot.meta[so + (in ? lane : 0)];
+    nib = (uint64_t)m.x | ((uint64_t)m.y << 32);
+    cat = (int)((m.z >> 16) & 0xFF);
+  } else if (kind == 1) {
+    const int L = (int)((dy >> 2) & 7u), s_ = (int)((dy >> 5) & 15u), gap = (int)((dy >> 9) & 7u);
+    const int mult = (int)((dy >> 12) & 3u);
+    cat = (int)((dy >> 14) & 31u);
+    const uint64_t unit = (cat == FOUR_TAKE_ONE || cat == FOUR_TAKE_TWO) ? 4ull : 3ull;  // main group: a quad, or `gap` triples
+    // c64[j]: the kicker positions of combination j as a nibble set over the REMAINS list (1 per kicker: g_c64); the
+    // main group's `gap` ranks are spliced in at nibble s_, `mult` cards per kicker (1 or 2: a shift)
+    const uint64_t c = c64[so + (in ? lane : 0)];
+    const uint64_t lowm = (1ull << (4 * s_)) - 1ull;
+    nib = (((unit * ONES) & ((1ull << (4 * gap)) - 1ull)) << (4 * s_)) + (((c & lowm) | ((c & ~lowm) << (4 * gap))) << (mult - 1));
+    (void)L;
+  } else {  // the joker-kicker extras (DDZ_NATIVE_JOKER_KICKERS builds): lanes 0..12 quad + jokers, 13..23 two triples + jokers
+    const uint32_t quads = (dy >> 2) & 0x1FFFu, pairs3 = dy >> 15;
+    const bool isq = lane < 13;
+    const int r = isq ? lane : (lane - 13) & 15;
+    ok = isq ? ((quads >> r) & 1u) : (lane < 24 && ((pairs3 >> r) & 1u));
+    nib = (isq ? (4ull << (4 * r)) : (0x33ull << (4 * r))) | (1ull << 52) | (1ull << 56);
+    cat = isq ? FOUR_TAKE_ONE : THREE_ONE_LINE;
+  }
+  const bool legal = ok && ((hand8 - nib) & H8) == H8;
+  const uint64_t bl = __ballot(legal);
+  if (WRITE && legal) {
+    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+    const int64_t pos = base + pre;
+    if (pos < cap) {
+      rows[pos] = unpack_row(nib, (uint32_t)cat);
+      if (IDS) ids[pos] = id;
+    }
+  }
+  return __popcll(bl);
 }
 
 // `face` of the tables of a chunk from their rows in LDS: element e = (table, plane, rank), one 16-byte store each,
@@ -1298,9 +1414,9 @@ static_assert(SLAB_CH == 16, "four lanes per table of a chunk in the list search
 #ifndef DDZ_SLAB_WAVES
 #define DDZ_SLAB_WAVES 4  // waves per SIMD the register budget of k_slab allows (5 / 6 spill: measured, not faster)
 #endif
-template <int MODE, bool IDS>
+template <int MODE, bool IDS, bool COOP>
 __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
-  Stamps<8> stamps;
+  Stamps<12> stamps;
   __shared__ HotTabT<false> hot;
   __shared__ uint4 s_chunk[WPB][SLAB_CH * DDZ_NFIELDS + SLAB_CH];  // per wave: the chunk's state rows + face side records
   const int lane = threadIdx.x & 63;
@@ -1308,13 +1424,21 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   const int64_t wave = (int64_t)blockIdx.x * WPB + wv;
   // one table per wave (T <= 4096): the lane-parallel phases of the block's 8 tables are run by wave 0 alone (otherwise
   // 16 waves per CU each issue them for ONE useful lane), the 8 waves then write one list each
-  const bool coop = a.coop != 0;
+  constexpr bool coop = COOP;  // (a template parameter: the two forms share no phase after the apply, and the team lists'
+                               //  registers would otherwise spill into the many-tables-per-wave form)
   const int64_t tb0 = (int64_t)blockIdx.x * WPB;  // coop: the block's tables
   const int cn = coop ? (tb0 < a.T ? (int)(a.T - tb0 < WPB ? a.T - tb0 : WPB) : 0) : 0;
   const int64_t tw0 = coop ? tb0 : wave * a.tpw;
   const int nw = coop ? (wv == 0 ? cn : 0)
                       : (tw0 < a.T ? (int)(a.T - tw0 < a.tpw ? a.T - tw0 : a.tpw) : 0);  // tables of this wave's lane-parallel phases
-  __shared__ uint4 s_share[WPB];  // coop: (hand, combo to beat, live) of the block's tables for the list phase
+  __shared__ uint4 s_share[WPB];  // coop: (hand | episode to deal, combo to beat, live | deal << 1) of the block's tables for the list phase
+  __shared__ uint4 s_item[WPB];   // coop: the lists the whole block writes: (hand, rounds, wave of the table)
+  __shared__ int s_nheavy;
+  __shared__ uint2 s_desc[COOP ? WPB : 1][TEAM_ROUNDS];     // per wave: the round records of its planned list (32 KB)
+  __shared__ uint32_t s_tcnt[COOP ? WPB : 1][TEAM_ROUNDS];  // ... and the rounds' sizes, then sizes | bases << 16 (16 KB)
+  __shared__ uint64_t s_c64[COOP ? COMBO_WORDS : 1];        // the kicker combinations as nibble sets (team_round; 10.7 KB)
+  __shared__ uint64_t s_keys[COOP ? WPB : 1][64];           // deal: the cards' keys (ranking by LDS broadcast reads)
+  if (coop && threadIdx.x == 0) s_nheavy = 0;  // (in front of the first barrier)
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
   constexpr bool SEARCH = MODE == DDZ_STEP_ROWS || MODE == DDZ_STEP_IDS;
   constexpr bool DRAWS = MODE == DDZ_STEP_RANDOM || MODE == DDZ_STEP_IDS;
@@ -1373,7 +1497,12 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       cnt_l = a.counts[t];
       if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
     }
-    if (first) hot_fill<TB>(hot);
+    // (one table per wave: wave 0 goes straight to the block's tables, the other fifteen fill the tables)
+    if (coop) { if (wv > 0) hot_fill<TB, HotTabT<false>, 64>(hot); }
+    else if (first) hot_fill<TB>(hot);
+    if (coop && wv > 0) {  // (while wave 0 decodes the block's tables)
+      for (int i = (int)threadIdx.x - 64; i < COMBO_WORDS; i += TB - 64) s_c64[i] = g_c64[i];
+    }
     uint32_t o_done = 0, o_illegal = 0, o_reward = 0;
     bool live = false;         // is there a list to write afterwards
     uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
@@ -1555,10 +1684,13 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       }
       // finished games with auto-reset: the next episode's deal (wave-wide), the lord leads
       uint64_t wr = a.auto_reset ? wm : 0ull;
-      const uint64_t deferred = lpt ? wr : 0ull;  // (work list: dealt in the list phase, by any wave of the block)
+      // (work list: dealt in the list phase, by any wave of the block; coop: by the table's own wave, the block's deals side
+      //  by side instead of one after the other in wave 0)
+      const bool defer = lpt || (coop && !(MODE == STEP_Q && a.face));  // (with `face` wave 0's face phase needs the dealt rows)
+      const uint64_t deferred = defer ? wr : 0ull;
       deal_l = (deferred >> lane) & 1ull;
       deal_ep = episode + 1u;
-      if (lpt) wr = 0ull;
+      if (defer) wr = 0ull;
       while (wr) {
         const int i = __builtin_ctzll(wr);
         wr &= wr - 1;
@@ -1578,7 +1710,9 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       if (64 + lane < nrows && ((stm >> ((64 + lane) / DDZ_NFIELDS)) & 1)) sp[64 + lane] = srow[64 + lane];
       if (128 + lane < nrows && ((stm >> ((128 + lane) / DDZ_NFIELDS)) & 1)) sp[128 + lane] = srow[128 + lane];
     }
-    if (coop && valid) s_share[lane] = make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, live ? 1u : 0u);
+    if (coop && valid)
+      s_share[lane] = deal_l ? make_uint4(deal_ep, 0u, LEAD, 3u)
+                             : make_uint4((uint32_t)qhand, (uint32_t)(qhand >> 32), qinfo, live ? 1u : 0u);
     }  // ntab > 0
     stamps.mark(3);
     if (first || lpt) __syncthreads();  // the hot records are in LDS (and the work list's counters are zero)
@@ -1604,14 +1738,117 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
     // ---- the lists of the (new) states, straight into the tables' slabs (nothing is staged: the rows in LDS stay valid)
     int n_l = 0;
     if (coop) {
+      stamps.mark(1);
+      bool heavy = false;  // this wave's list is written by the block below
       if (wv < cn) {  // this wave's table of the block
         const uint4 sh = s_share[wv];
+        const uint32_t fw = rfl(sh.w);
+        const int64_t tt = tb0 + wv;
         int n = 0;
-        if (sh.w) n = slab_list<IDS>((uint64_t)rfl(sh.x) | ((uint64_t)rfl(sh.y) << 32), rfl(sh.z), (tb0 + wv) * a.stride, a.stride, a.rows,
-                                     a.ids, hot, lane, fl, a.status);
-        if (lane == 0) a.counts[tb0 + wv] = n;
+        if (fw & 1u) {
+          uint64_t hand = (uint64_t)rfl(sh.x) | ((uint64_t)rfl(sh.y) << 32);
+          const uint32_t qi = rfl(sh.z);
+          if (fw & 2u) {  // a finished game: the next episode's deal (native prepare(), spec v2), the lord leads
+            const uint32_t ep = rfl(sh.x);
+            uint64_t h0, h1, h2;
+            deal_wave_lds(a.gid_base + (uint64_t)tt, ep, a.k0, a.k1, lane, s_keys[wv], h0, h1, h2);
+            if (lane < DDZ_NFIELDS)
+              ((uint4*)(a.state + tt * STATE_ROW_BYTES))[lane] =
+                  lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
+                  : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, ep, 0) : make_uint4(0, 0, 0, 0);
+            hand = h1;
+            stamps.mark(7);
+          }
+          // A lead from a hand with two triples or a bomb (kicker blocks: many scan rounds) is planned into round records;
+          // from TEAM_MIN rounds on the block executes them together -- a launch of <= 4096 tables lasts as long as its
+          // slowest list -- below that the wave executes its records itself.
+          // (measured, tools/slab_coop_probe.py: planning every lead with a triple, or every lead, changes nothing -- 10.1 us
+          //  per launch at 4096 tables either way; thresholds 3 .. 8 are equal, 16 costs 1.6 us, no block lists 1.2 us)
+          const int thr = a.team;
+          if (thr && hand != 0 && (qi & 0xFF) == EMPTY && !(qi & (QF_FROZEN | QF_BADLAST)) &&
+              (__builtin_popcount(ge_mask(hand, 3)) >= 2 || ge_mask(hand, 4) != 0)) {
+            const Out o{a.rows, a.ids, tt * a.stride, (tt + 1) * a.stride, nullptr, nullptr, nullptr};
+            stamps.mark(4);
+            Pick pk{-1, 0, 0, 0, 0};
+            pk.desc = s_desc[wv];
+            plan_scan_t<EM_TEAM_PLAN, IDS, true>(hand, follow_of(qi), hot, lane, o, pk);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int R = pk.rc;
+            stamps.mark(8);
+            if (R > TEAM_ROUNDS) {  // cannot happen (see team_round): flagged, an empty list
+              if (lane == 0 && a.status) atomicOr(a.status, 2);
+            } else if (R >= thr) {
+              heavy = true;
+              if (lane == 0) s_item[atomicAdd(&s_nheavy, 1)] = make_uint4((uint32_t)hand, (uint32_t)(hand >> 32), (uint32_t)R, (uint32_t)wv);
+            } else {
+              const uint64_t hand8 = hand | 0x8888888888888888ull;
+              for (int r = 0; r < R; ++r)
+                n += team_round<true, IDS>(s_desc[wv][r], hand8, hot, s_c64, lane, o.base + n, o.cap, a.rows, a.ids);
+              if (n > a.stride) {
+                if (lane == 0 && a.status) atomicOr(a.status, 2);
+                n = 0;
+              }
+              stamps.mark(9);
+            }
+          } else {
+            n = slab_list<IDS>(hand, qi, tt * a.stride, a.stride, a.rows, a.ids, hot, lane, fl, a.status);
+          }
+        }
+        if (lane == 0 && !heavy) a.counts[tt] = n;
         s_rows += n;
       }
+      stamps.mark(4);
+      __syncthreads();
+      const int nh = s_nheavy;
+      stamps.mark(6);
+      if (nh > 0) {  // (block-uniform)
+        // pass 1: the rounds of every heavy list dealt out over the sixteen waves, their sizes into s_tcnt
+        for (int h = 0; h < nh; ++h) {
+          const uint4 e = s_item[h];
+          const uint64_t hand8 = ((uint64_t)rfl(e.x) | ((uint64_t)rfl(e.y) << 32)) | 0x8888888888888888ull;
+          const int R = (int)rfl(e.z), ow = (int)rfl(e.w);
+          for (int r = (wv + 5 * h) & (WPB - 1); r < R; r += WPB) {
+            const int k = team_round<false, IDS>(s_desc[ow][r], hand8, hot, s_c64, lane, 0, 0, a.rows, a.ids);
+            if (lane == 0) s_tcnt[ow][r] = (uint32_t)k;
+          }
+        }
+        stamps.mark(10);
+        __syncthreads();
+        // exclusive scan of a list's round sizes, in place (wave h: list h); its size to counts[]
+        if (wv < nh) {
+          const uint4 e = s_item[wv];
+          const int R = (int)rfl(e.z), ow = (int)rfl(e.w);
+          int run = 0;
+          for (int r0 = 0; r0 < R; r0 += 64) {
+            const int i = r0 + lane;
+            const int v = i < R ? (int)s_tcnt[ow][i] : 0;
+            const int inc = wave_scan_add(v);
+            if (i < R) s_tcnt[ow][i] = (uint32_t)v | (uint32_t)(run + inc - v) << 16;  // size | base << 16
+            run += (int)rl((uint32_t)inc, 63);
+          }
+          if (run > a.stride) {  // cannot happen for a <= 20-card hand (tools/max_legal_bound.c)
+            if (lane == 0 && a.status) atomicOr(a.status, 2);
+            run = 0;
+          }
+          if (lane == 0) a.counts[tb0 + ow] = run;
+          s_rows += run;
+        }
+        __syncthreads();
+        // pass 2: the same rounds again, rows written at their bases
+        for (int h = 0; h < nh; ++h) {
+          const uint4 e = s_item[h];
+          const uint64_t hand8 = ((uint64_t)rfl(e.x) | ((uint64_t)rfl(e.y) << 32)) | 0x8888888888888888ull;
+          const int R = (int)rfl(e.z), ow = (int)rfl(e.w);
+          const int64_t base = (tb0 + ow) * a.stride;
+          for (int r = (wv + 5 * h) & (WPB - 1); r < R; r += WPB) {
+            const uint32_t cb = rfl(s_tcnt[ow][r]);
+            if (cb & 0xFFFFu)  // (a round without a legal id -- most rounds of a kicker block -- is not repeated)
+              team_round<true, IDS>(s_desc[ow][r], hand8, hot, s_c64, lane, base + (int)(cb >> 16), base + a.stride, a.rows, a.ids);
+          }
+        }
+      }
+      stamps.mark(11);
     }
     if (lpt) {
       const int n0 = s_wcnt[0], n1 = n0 + s_wcnt[1], n2 = n1 + s_wcnt[2], n3 = n2 + s_wcnt[3];
@@ -2445,6 +2682,7 @@ struct ddz_env {
   bool counts_valid;
   int64_t legal_cap;  // capacity of the row buffer the last ddz_legal wrote
   int slab_coop;      // k_slab with one table per wave: wave 0 of a block runs the block's lane-parallel phases
+  int slab_team;      // ... and the block writes its heavy lists together
   uint32_t auto_next; // next slot of the k_auto2 queue ring
   int slab_lpt;       // k_slab: block work list of deals + lists, heaviest first (tpw >= 2)
   int auto_teams;     // k_auto2: waves without tables help the searches of their block
@@ -2656,6 +2894,7 @@ int ddz_create(ddz_env_t** out, int64_t T, uint64_t seed, uint64_t gid_base, int
   e->parity = 0; e->counts_valid = false; e->legal_cap = 0;
   e->slab_coop = e->tpw == 1;
   e->slab_lpt = e->tpw >= 2;
+  e->slab_team = 5;
   e->rollout_waves = 12;
   e->auto_teams = 2;   // teams at the queue's end (1 = also team-first for the predicted-heaviest: measured, no gain -- DESIGN.md 9)
   *out = e;
@@ -2745,13 +2984,18 @@ int ddz_step_slab(ddz_env_t* e, int mode, const void* sel, int32_t* counts, int8
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = 0; a.choice_out = nullptr; a.face = nullptr; a.face_variant = 0;
-  a.coop = e->slab_coop; a.lpt = e->slab_lpt;
+  a.coop = e->slab_coop; a.lpt = e->slab_lpt; a.team = e->slab_team;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-#define DDZ_LAUNCH_SLAB(M)                                                              \
-  do {                                                                                  \
-    if (ids) hipLaunchKernelGGL((k_slab<M, true>), grid, block, 0, st, a);              \
-    else hipLaunchKernelGGL((k_slab<M, false>), grid, block, 0, st, a);                 \
+#define DDZ_LAUNCH_SLAB(M)                                                                    \
+  do {                                                                                        \
+    if (a.coop) {                                                                             \
+      if (ids) hipLaunchKernelGGL((k_slab<M, true, true>), grid, block, 0, st, a);            \
+      else hipLaunchKernelGGL((k_slab<M, false, true>), grid, block, 0, st, a);               \
+    } else {                                                                                  \
+      if (ids) hipLaunchKernelGGL((k_slab<M, true, false>), grid, block, 0, st, a);           \
+      else hipLaunchKernelGGL((k_slab<M, false, false>), grid, block, 0, st, a);              \
+    }                                                                                         \
   } while (0)
   switch (mode) {
     case DDZ_STEP_RANDOM: DDZ_LAUNCH_SLAB(DDZ_STEP_RANDOM); break;
@@ -2780,10 +3024,15 @@ int ddz_policy_step_slab(ddz_env_t* e, const float* q, double epsilon, int32_t* 
   a.done = done; a.reward = reward; a.illegal = illegal; a.traj = (uint4*)traj;
   a.wave_stats = e->sc.blk_stats; a.status = e->sc.status;
   a.thr = (uint64_t)(epsilon * 4294967296.0); a.choice_out = choice; a.face = (float4*)face; a.face_variant = face_variant;
-  a.coop = e->slab_coop; a.lpt = e->slab_lpt;
+  a.coop = e->slab_coop; a.lpt = e->slab_lpt; a.team = e->slab_team;
   const dim3 grid((unsigned)e->nblocks), block(TB);
-  if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_slab<STEP_Q, false>), grid, block, 0, (hipStream_t)stream, a);
+  if (a.coop) {
+    if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_slab<STEP_Q, false, true>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    if (ids) hipLaunchKernelGGL((k_slab<STEP_Q, true, false>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_slab<STEP_Q, false, false>), grid, block, 0, (hipStream_t)stream, a);
+  }
   e->counts_valid = false;
   return check_launch();
 }
@@ -3130,10 +3379,10 @@ int ddz_debug_auto_choose_state(ddz_env_t* e, int kernel, int auto_roles, int32_
 }
 
 // test hook: the launch geometry of a handle's table kernels -- tables per wave (1..64, 0 = keep) and whether k_slab runs
-// the one-table-per-wave block-cooperative form (0 / 1, -1 = keep).  Results never depend on either (tests sweep them).
+// the one-table-per-wave block-cooperative form (0 / 1, 2 = without the block-written heavy lists, n > 2 = those from n scan rounds on (default 5), -1 = keep).  Results never depend on either (tests sweep them).
 int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int slab_work_list) {
   if (!good(e)) return DDZ_EHANDLE;
-  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > 1 || slab_work_list < -1 || slab_work_list > 1)
+  if (tables_per_wave < 0 || tables_per_wave > 64 || slab_coop < -1 || slab_coop > TEAM_ROUNDS || slab_work_list < -1 || slab_work_list > 1)
     return DDZ_EINVAL;
   if (tables_per_wave > 0) {
     e->tpw = tables_per_wave;
@@ -3143,6 +3392,7 @@ int ddz_debug_set_geometry(ddz_env_t* e, int tables_per_wave, int slab_coop, int
     e->rollout_waves = WPB;   // (an explicit geometry also holds for the rollout: 16-wave blocks, this many tables per wave)
   }
   e->slab_coop = e->tpw == 1 && (slab_coop < 0 ? e->slab_coop || tables_per_wave > 0 : slab_coop) ? 1 : 0;
+  if (slab_coop >= 0) e->slab_team = slab_coop == 2 ? 0 : slab_coop > 2 ? slab_coop : 5;
   if (slab_work_list >= 0) e->slab_lpt = slab_work_list && e->tpw >= 2;
   return DDZ_OK;
 }

@@ -100,7 +100,7 @@ class BatchedEnv:
         if _debug_tables_per_wave is not None or _debug_slab_coop is not None or _debug_slab_work_list is not None:
             # test hook: results never depend on the launch geometry
             check(self.lib.ddz_debug_set_geometry(h, int(_debug_tables_per_wave or 0),
-                                                  -1 if _debug_slab_coop is None else int(bool(_debug_slab_coop)),
+                                                  -1 if _debug_slab_coop is None else int(_debug_slab_coop),
                                                   -1 if _debug_slab_work_list is None else int(bool(_debug_slab_work_list))))
         if _debug_auto_teams is not None:
             # test hook: auto_choose's wavefronts without tables help their workgroup's running searches (default) or not

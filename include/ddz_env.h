@@ -375,7 +375,8 @@ int ddz_debug_auto_leaf(int device_id, const int32_t* in, const double* rp, int6
  * 3 = the same kernel in table order.  Same ids by construction.                                                  */
 int ddz_debug_auto_choose_state(ddz_env_t* env, int kernel, int auto_roles, int32_t* ids, int64_t* stats, void* stream);
 /* test hook: launch geometry of a handle (tables per wavefront 1..64, 0 = keep; block-cooperative one-table-per-wave
- * form of ddz_step_slab 0 / 1, -1 = keep; ddz_step_slab's block work list of deals + lists -- most expensive first --
+ * form of ddz_step_slab 0 / 1, 2 = that form with every list written by one wavefront (1: leads of 5 or more scan rounds
+ * -- plane-rich hands, the lord's first lead -- are written by the whole workgroup; n > 2: from n rounds on), -1 = keep; ddz_step_slab's block work list of deals + lists -- most expensive first --
  * 0 / 1, -1 = keep).  Call right after ddz_create.  Results never depend on it; the library reads no environment
  * variables.                                                                                                     */
 int ddz_debug_set_geometry(ddz_env_t* env, int tables_per_wave, int slab_coop, int slab_work_list);

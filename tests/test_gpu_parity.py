@@ -795,6 +795,46 @@ def test_slab_api_lockstep_vs_oracle(pkg, oracle, T, iters, seed, base):
     assert st["plies"] > 0 and st["episodes"] > 0
 
 
+@pytest.mark.parametrize("T,want_ids", [(1500, True), (4096, False), (37, True)])
+def test_slab_block_written_lists_equal_single_wave_lists(pkg, oracle, T, want_ids):
+    """One table per wave (T <= 4096): the lists of plane-rich leads -- the lord's 20-card lead of a fresh game above all
+    -- are written by all sixteen waves of the block (slab_list_team: the scan rounds dealt out, counted, scanned, written
+    at their bases), every other list by the table's own wave, deals by the table's wave.  Same games, byte-identical
+    slabs as the form in which one wave writes each list (ddz_debug_set_geometry slab_coop = 2) and as the
+    many-tables-per-wave form; the heaviest lists against the oracle."""
+    a = pkg.BatchedEnv(T, seed=77, device=_dev(), want_ids=want_ids)                              # block-written heavy lists
+    b = pkg.BatchedEnv(T, seed=77, device=_dev(), want_ids=want_ids, _debug_slab_coop=2)          # one wave per list
+    c = pkg.BatchedEnv(T, seed=77, device=_dev(), want_ids=want_ids, _debug_tables_per_wave=3)    # work-list form
+    ref = oracle.OracleEnv(T, seed=77)
+    for e in (a, b, c):
+        e.reset(); e.legal_slab()
+    ref.reset()
+    S = a.slab_stride
+    heavy_seen = 0
+    for it in range(260):
+        for e in (a, b, c):
+            e.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
+        ref.legal(); ref.step(oracle.STEP_RANDOM, None, auto_reset=True)
+        ca = a.counts.cpu().numpy()
+        assert np.array_equal(ca, b.counts.cpu().numpy()) and np.array_equal(ca, c.counts.cpu().numpy()), it
+        take = (torch.arange(S, device=_dev())[None, :] < a.counts[:, None]).reshape(-1)
+        n = T * S   # (the buffers are sized for the largest stride: rows [cap][16], ids [cap])
+        assert torch.equal(a.rows[:n][take], b.rows[:n][take]) and torch.equal(a.rows[:n][take], c.rows[:n][take]), it
+        if want_ids:
+            assert torch.equal(a.ids[:n][take], b.ids[:n][take]) and torch.equal(a.ids[:n][take], c.ids[:n][take]), it
+        assert torch.equal(a.state, b.state) and torch.equal(a.state, c.state), it
+        heavy_seen += int((ca > 60).sum())
+        if it % 13 == 0 or it > 250:
+            roff, rrows, rids = ref.legal()
+            assert np.array_equal(a.state.cpu().numpy(), ref.state), it
+            assert np.array_equal(ca, np.diff(roff)), it
+            assert np.array_equal(a.rows[:n].cpu().numpy()[take.cpu().numpy()], rrows), it
+            if want_ids:
+                assert np.array_equal(a.ids[:n].cpu().numpy()[take.cpu().numpy()], rids), it
+    assert heavy_seen > 0 and a.status() == 0 and b.status() == 0 and c.status() == 0
+    assert a.stats() == b.stats() == c.stats()
+
+
 def test_slab_api_random_equals_rollout(pkg):
     """step_slab(STEP_RANDOM) plays the same games as rollout_random / step_random (same engine RNG)."""
     a = pkg.BatchedEnv(1500, seed=21, device=_dev())

@@ -62,7 +62,7 @@ for T in (65536, 4096):
         st = stats_rows(f"slab/{mode}_{T}_stats", "k_slab")
         if not c and not st:
             continue
-        e = {"tables": T, "mode": mode, "kernel": kern}
+        e = {"tables": T, "mode": mode, "kernel": kern[:-1] + (", true>" if T <= 4096 else ", false>")}   # <MODE, IDS, COOP>
         if st:
             e["launches"] = int(st[0]["Calls"]); e["avg_us"] = float(st[0]["AverageNs"]) / 1e3
             rows_csv.append({"tables": T, "mode": mode, **st[0]})

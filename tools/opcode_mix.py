@@ -22,8 +22,9 @@ LIB = os.path.join(ROOT, "doudizhu-rl_amd", "csrc", "libddz_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 KERNELS = {  # short name -> substring of the mangled kernel name
     "k_rollout<false,false>": "9k_rolloutILb0ELb0EE", "k_rollout<false,true>": "9k_rolloutILb0ELb1EE",
-    "k_slab<0,true>": "6k_slabILi0ELb1EE", "k_slab<1,true>": "6k_slabILi1ELb1EE", "k_slab<3,true>": "6k_slabILi3ELb1EE",
-    "k_slab<4,true>": "6k_slabILi4ELb1EE", "k_auto2<true>": "7k_auto2ILb1EE", "k_table<3,0,false>": "7k_tableILi3ELi0ELb0EE",
+    # k_slab<MODE, IDS, COOP>: the many-tables-per-wave form (COOP = false: every batch above 4096 tables) keeps its two-argument key
+    "k_slab<0,true>": "6k_slabILi0ELb1ELb0EE", "k_slab<1,true>": "6k_slabILi1ELb1ELb0EE", "k_slab<3,true>": "6k_slabILi3ELb1ELb0EE",
+    "k_slab<4,true>": "6k_slabILi4ELb1ELb0EE", "k_slab<0,true,coop>": "6k_slabILi0ELb1ELb1EE", "k_auto2<true>": "7k_auto2ILb1EE", "k_table<3,0,false>": "7k_tableILi3ELi0ELb0EE",
     "k_moves_slab<true>": "12k_moves_slabILb1EE", "k_mask": "6k_maskE",
 }
 HALF = re.compile(r"^v_(lshlrev_b64|lshrrev_b64|ashrrev_i64|mul_lo_|mul_hi_|mbcnt|cmp|cmpx|add_co|addc_co|sub_co|subb_co|"

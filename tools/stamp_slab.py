@@ -50,6 +50,23 @@ for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["40
         print(f"  {nm:36s} mean {per.mean():8.0f}  p50 {np.percentile(per, 50):8.0f}  p99 {np.percentile(per, 99):8.0f}  max {per.max():8.0f}")
     tw = s[:, :5].sum(1)
     print(f"  total per wave mean {tw.mean():8.0f} cycles  p50 {np.percentile(tw, 50):8.0f}  p99 {np.percentile(tw, 99):8.0f}  max {tw.max():8.0f}")
+    if T <= 4096:
+        # one table per wave: wave 0 of a block decodes / applies the block's 16 tables, then every wave deals (if its game
+        # ended) and writes its table's list, then the block writes its heavy lists together
+        full = buf.cpu().numpy().astype(np.float64)
+        w0 = full[0::16]
+        w0 = w0[w0[:, 5] > 0]
+        rest = np.concatenate([full[k::16] for k in range(1, 16)])
+        rest = rest[rest[:, 5] > 0]
+        for nm, x in (("wave 0 of a block", w0), ("waves 1..15", rest)):
+            print(f"  {nm}: {len(x)} waves")
+            for k, ph in ((0, "prologue"), (2, "decode + selection (16 tables)"), (3, "apply / hot fill"), (1, "wait for wave 0"),
+                          (7, "deal"), (4, "own list + outputs"), (8, "plan of a rich lead"), (9, "its rounds by the wave itself"),
+                          (6, "wait for the block's lists"), (10, "block lists: pass 1"), (11, "block lists: wait, scan, pass 2")):
+                v = x[:, k]
+                print(f"    {ph:32s} mean {v.mean():8.0f}  p50 {np.percentile(v, 50):8.0f}  p99 {np.percentile(v, 99):8.0f}  max {v.max():8.0f}   nonzero {int((v > 0).sum())}")
+            tot = x[:, [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11]].sum(1)
+            print(f"    {'total':32s} mean {tot.mean():8.0f}  p50 {np.percentile(tot, 50):8.0f}  p99 {np.percentile(tot, 99):8.0f}  max {tot.max():8.0f}")
     # the fused policy iteration (ddz_policy_step_slab): arg-max in the prologue, `face` between apply and lists
     q = torch.rand((T, env.slab_stride), dtype=torch.float32, device="cuda")
     face = torch.empty((T, 6, 15, 4), dtype=torch.float32, device="cuda")
