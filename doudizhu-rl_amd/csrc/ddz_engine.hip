@@ -1164,7 +1164,11 @@ __global__ __launch_bounds__(RW * 64, RW == WPB ? 4 : 6) void k_rollout(RolloutA
           uint32_t dk0 = a.k0, dk1 = a.k1;
           asm volatile("" : "+s"(dk0), "+s"(dk1));
           uint64_t h0, h1, h2;
+#ifdef DDZ_ROLLOUT_DEAL_READLANE
           deal_wave(gid, episode, dk0, dk1, lane, h0, h1, h2);
+#else
+          deal_wave_lds(gid, episode, dk0, dk1, lane, stage, h0, h1, h2);  // (the staging list is idle between two lists)
+#endif
           hc = h1; hn = h2; hp = h0;  // the lord (role 1) moves first, then down (2), then up (0)
           R = lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
               : lane == DDZ_F_META ? make_uint4(1u | (0xFFu << 16), 1u << 16, episode, 0) : make_uint4(0, 0, 0, 0);
