@@ -230,6 +230,34 @@ def other_config_legs(pkg, torch, dev, errors):
 
     # (0) configs[1] exactly as BASELINE.json writes it: 4096 tables, random policy, legal-move list only
     leg("tables_4096_random_rollout", lambda: rollout_leg(pkg, torch, dev, 4096, "k_rollout"))
+
+    # (0b) the launch a policy drives at that size: step_slab(RANDOM) at 4096 tables = one table per wavefront -- a launch that
+    # lasts as long as its slowest list (k_slab<0,true,true>: deals by the tables' waves, plane-rich leads written by the block)
+    def step_slab_4096_leg():
+        e4 = pkg.BatchedEnv(4096, seed=0, device=dev)
+        e4.reset()
+        e4.rollout_random(200)
+        e4.legal_slab()
+        s0 = e4.stats()
+        dt, reps = timed_loop(lambda: [e4.step_slab(None, pkg.STEP_RANDOM, auto_reset=True) for _ in range(50)], sync)
+        s1 = e4.stats()
+        a = (s1["legal_rows"] - s0["legal_rows"]) / max(1, s1["plies"] - s0["plies"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2000):
+            e4.step_slab(None, pkg.STEP_RANDOM, auto_reset=True)
+        e1.record()
+        sync()
+        per = e0.elapsed_time(e1) * 1e-3 / 2000      # HIP events around 2000 back-to-back launches on the launching stream
+        b = 260 + 20 * a
+        assert e4.status() == 0
+        return {"env_steps_per_s": 4096 * 50 * reps / dt, "us_per_iteration": dt / (50 * reps) * 1e6, "us_per_launch_events": per * 1e6,
+                "mean_legal_moves": a,
+                "roofline": hbm_block("k_slab<0,true,true>", b * 4096, per, algorithmic_bytes_per_env_step=b,
+                                      issue=issue_block("k_slab_random_4096", 4096, per)),
+                "loop": "step_slab(RANDOM), 4096 tables: latency-bound (256 blocks of 16 waves, one table per wave)"}
+
+    leg("tables_4096_step_slab_only", step_slab_4096_leg)
     env = pkg.BatchedEnv(T, seed=0, device=dev)
     env.reset()
     env.rollout_random(200)

@@ -1091,11 +1091,21 @@ __global__ __launch_bounds__(RW * 64, RW == WPB ? 4 : 6) void k_rollout(RolloutA
         stamps.mark(5);
         idx = (int)__umulhi(draw, (uint32_t)n);  // random.choice(actions), envi.py:83 (n >= 1: pass)
         const int src = __builtin_ctz((uint32_t)__ballot(pre == idx) & okm);
-        c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
         const int sr = (src < 16 ? src - 1 : src - 16) & 15;
+#ifndef DDZ_ROLLOUT_PICK_SCALAR
+        c = make_uint4(rl(row.x, src), rl(row.y, src), rl(row.z, src), rl(row.w, src));
+#endif
         if (src == 0) { snib = 0; scat = EMPTY; svlv = 1u << 8; }
         else if (src == 29) { snib = (1ull << 52) | (1ull << 56); scat = BIGBANG; svlv = 100u | (1u << 8); ncards = 2; }
         else { scat = src < 16 ? (uint32_t)lc0 : (uint32_t)QUADRIC; snib = (uint64_t)scat << (4 * sr); svlv = (uint32_t)sr | (1u << 8); ncards = scat; }
+#ifdef DDZ_ROLLOUT_PICK_SCALAR
+        {  // the chosen row from the chosen lane's number, scalar arithmetic instead of four v_readlane: measured SLOWER (3.78
+           // against 4.06 G env steps/s at 65,536 tables: the CU's scalar unit is the busier one); kept for the record
+          const uint32_t cp = (src == 0 || src == 29) ? 0u : scat, dvs = cp << (8 * (sr & 3)), wq = (uint32_t)sr >> 2;
+          c = make_uint4(wq == 0 ? dvs : 0u, wq == 1 ? dvs : 0u, wq == 2 ? dvs : 0u,
+                         (wq == 3 ? dvs : 0u) | (cp << 24) | (src == 29 ? (0x00010100u | ((uint32_t)BIGBANG << 24)) : 0u));
+        }
+#endif
         stamps.mark(5);  // fast path: list + pick
       } else {
         const Out o{nullptr, nullptr, 0, 0, stage, svl, sid};

@@ -1027,6 +1027,8 @@ def test_bench_contract():
         assert legs[k]["env_steps_per_s"] > 1e6, (k, legs[k])
         rf = legs[k]["roofline"]                                  # every leg carries the roof of its dominant kernel
         assert rf["bound"] in ("hbm", "mfma") and rf["peak"] in (8000.0, 157.3) and 0 < rf["frac"] < 1 and rf["launch_us"] > 0, k
+    s4 = legs["tables_4096_step_slab_only"]                       # the policy-driven launch at configs[1]'s size (one table per wave)
+    assert s4["env_steps_per_s"] > 1e8 and 0 < s4["us_per_launch_events"] < 14 and s4["roofline"]["kernel"] == "k_slab<0,true,true>"
     small = legs["tables_4096_random_rollout"]                    # configs[1] as BASELINE.json writes it
     assert small["roofline"]["env_steps_per_launch"] == 4096 * 1000 and small["csr_env_steps_per_s"] > 1e8
     for k in ("tables_65536_step_slab_only", "tables_65536_rule_opponent", "tables_65536_policy_loop_fused"):

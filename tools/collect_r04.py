@@ -236,6 +236,8 @@ if slab["kernels"]:
             pk[name].update({"valu_per_unit": k["SQ_INSTS_VALU_per_table_step"], "salu_per_unit": k["SQ_INSTS_SALU_per_table_step"],
                              "branch_per_unit": k["SQ_INSTS_BRANCH_per_table_step"], "wait_any_share": k["wait_any_share_of_wave_cycles"],
                              "source": "profiles/r04_slab_pmc.json (pass `slab`)"})
+            if key == "random_4096":
+                pk[name]["mix_key"] = "k_slab<0,true,coop>"   # one table per wave: k_slab<0, true, true>
 ap = os.path.join(P, "r04_auto_pmc.json")
 if os.path.exists(ap):
     a4 = json.load(open(ap))
