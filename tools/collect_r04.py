@@ -226,6 +226,8 @@ for key in fresh:   # (only when this run held a fresh `rollout` pass)
   t4 = fresh[key]["valu"]
   pk.setdefault(key, dict(pk["k_rollout"]))
   pk[key]["tables"] = 4096 if key == "k_rollout" else 65536
+  pk[key]["mix_key"] = "k_rollout<false,false,16 waves>" if key == "k_rollout" else "k_rollout<false,false>"   # (4096 tables: 16-wave blocks)
+  pk[key]["waves_per_simd"] = 4 if key == "k_rollout" else 6
   pk[key].update({"valu_per_unit": t4["SQ_INSTS_VALU_per_env_step"], "salu_per_unit": t4["SQ_INSTS_SALU_per_env_step"],
                         "branch_per_unit": t4["SQ_INSTS_BRANCH_per_env_step"], "wait_any_share": t4["SQ_WAIT_ANY_share_of_wave_cycles"],
                         "clock_GHz": t4["clock_GHz"], "source": "profiles/pmc_traffic.json (pass `rollout`: " + t4["workload"] + ")"})

@@ -21,7 +21,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "doudizhu-rl_amd", "csrc", "libddz_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 KERNELS = {  # short name -> substring of the mangled kernel name
-    "k_rollout<false,false>": "9k_rolloutILb0ELb0EE", "k_rollout<false,true>": "9k_rolloutILb0ELb1EE",
+    # k_rollout<IDS, TRAJ, STAGED, waves per block>: the two-argument keys are the 12-wave blocks of the headline (65,536 tables)
+    "k_rollout<false,false>": "9k_rolloutILb0ELb0ELb0ELi12EE", "k_rollout<false,true>": "9k_rolloutILb0ELb1ELb0ELi12EE",
+    "k_rollout<false,false,16 waves>": "9k_rolloutILb0ELb0ELb0ELi16EE",
     # k_slab<MODE, IDS, COOP>: the many-tables-per-wave form (COOP = false: every batch above 4096 tables) keeps its two-argument key
     "k_slab<0,true>": "6k_slabILi0ELb1ELb0EE", "k_slab<1,true>": "6k_slabILi1ELb1ELb0EE", "k_slab<3,true>": "6k_slabILi3ELb1ELb0EE",
     "k_slab<4,true>": "6k_slabILi4ELb1ELb0EE", "k_slab<0,true,coop>": "6k_slabILi0ELb1ELb1EE", "k_auto2<true>": "7k_auto2ILb1EE", "k_table<3,0,false>": "7k_tableILi3ELi0ELb0EE",
