@@ -235,13 +235,25 @@ __global__ __launch_bounds__(64) void k_build_table(int32_t* status) {
 // record fetched from memory costs ~1000 cycles; staged once per block it costs an LDS read.
 constexpr int HOT_IDS = ID_THREE_ONE_LINE;  // 526
 constexpr int HOT_SLOTS = HOT_IDS + 1;
-template <bool WITH_ROWS>
-struct HotTabT {  // WITH_ROWS = false: kernels that stage packed rows only (k_rollout) save 8.4 KB of LDS
-  static constexpr bool HAS_ROWS = WITH_ROWS;
+// WITH_ROWS = false: kernels that stage packed rows only (k_rollout) save 8.4 KB of LDS.  C64 (DDZ_HOT_C64): the kicker
+// combinations as 8-byte nibble sets over the remains list (g_c64) instead of 4-byte position words (g_combo): a kicker
+// candidate is then a splice (two masks, a shift, an or) instead of a loop over its 2 - 5 positions, for 5.3 KB more LDS
+// (k_auto / k_auto2 keep the words: their blocks have no LDS left).
+template <bool WITH_ROWS, bool C64 = false>
+struct HotTabT {
+  static constexpr bool HAS_ROWS = WITH_ROWS, HAS_C64 = C64;
   uint4 meta[HOT_SLOTS + 1];
   uint4 rows[WITH_ROWS ? HOT_SLOTS + 1 : 1];
-  uint32_t combo[COMBO_WORDS + 2];
+  uint32_t combo[C64 ? 2 : COMBO_WORDS + 2];
+  uint64_t c64[C64 ? COMBO_WORDS + 1 : 1];
 };
+#ifndef DDZ_HOT_C64
+#define DDZ_HOT_C64 1
+#endif
+// Measured (tools/lib_ab_probe.py, both builds): the stress set of plane-rich leads through k_moves_slab 305 -> 244 us; k_rollout
+// unchanged at 65,536 tables (16.06 / 16.10 us per iteration), + 0.8 % at 4096; the many-tables form of k_slab 27.4 -> 27.9 us
+// (a larger fill, 85 KB of LDS): so the nibble sets are used by k_moves_slab and by the one-table-per-wave form of k_slab.
+using HotTabL = HotTabT<false, DDZ_HOT_C64 != 0>;
 using HotTab = HotTabT<true>;
 
 // componentwise select (a ?: on whole uint4s is lowered to a lane-indexed scratch array)
@@ -351,11 +363,18 @@ __device__ __forceinline__ int scan_combos(int list, int count, int idb, uint64_
   for (int j0 = 0; j0 < count; j0 += 64) {
     const int j = j0 + lane;
     const bool in = j < count;
-    const uint32_t e = hot.combo[off + (in ? j : 0)];
     uint64_t nib = mainnib;
-    for (int k = 0; k < L; ++k) {
-      const int pos = (e >> (4 * k)) & 15;
-      nib += (uint64_t)mult << (4 * (pos < s ? pos : pos + gap));
+    if constexpr (HT::HAS_C64) {
+      // the kicker positions as a nibble set over the REMAINS list; the main group's `gap` ranks are spliced in at nibble s,
+      // `mult` cards per kicker (1 or 2: a shift)
+      const uint64_t c = hot.c64[off + (in ? j : 0)], lowm = (1ull << (4 * s)) - 1ull;
+      nib += ((c & lowm) | ((c & ~lowm) << (4 * gap))) << (mult - 1);
+    } else {
+      const uint32_t e = hot.combo[off + (in ? j : 0)];
+      for (int k = 0; k < L; ++k) {
+        const int pos = (e >> (4 * k)) & 15;
+        nib += (uint64_t)mult << (4 * (pos < s ? pos : pos + gap));
+      }
     }
     const bool sub = ((hand8 - nib) & H8) == H8;
     const uint4 row = ROWS ? unpack_row(nib, (uint32_t)cat) : make_uint4(0, 0, 0, 0);
@@ -531,7 +550,10 @@ __device__ __forceinline__ void hot_fill(HT& hot) {
     if (HT::HAS_ROWS) hot.rows[i] = g_tab[2 * id];
   }
 #pragma unroll
-  for (int i = (int)threadIdx.x - OFF; i < COMBO_WORDS; i += NT - OFF) hot.combo[i] = g_combo[i];
+  for (int i = (int)threadIdx.x - OFF; i < COMBO_WORDS; i += NT - OFF) {
+    if constexpr (HT::HAS_C64) hot.c64[i] = g_c64[i];
+    else hot.combo[i] = g_combo[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1317,8 +1339,8 @@ __device__ __forceinline__ int slab_list(uint64_t hand, uint32_t info, int64_t b
 // run -- a <= 20-card hand holds <= 6 triples: <= 15 blocks of <= 6 rounds per plane category --, the rocket, <= 5 quads x
 // (2 + 2): ~210 at most, TEAM_ROUNDS = 256; a plan with more sets status bit 1 and writes an empty list.
 template <bool WRITE, bool IDS, class HT>
-__device__ __forceinline__ int team_round(uint2 d, uint64_t hand8, const HT& hot, const uint64_t* c64, int lane, int64_t base,
-                                          int64_t cap, uint4* rows, int32_t* ids) {
+__device__ __forceinline__ int team_round(uint2 d, uint64_t hand8, const HT& hot, int lane, int64_t base, int64_t cap, uint4* rows,
+                                          int32_t* ids) {
   constexpr uint64_t H8 = 0x8888888888888888ull;
   const uint32_t dx = rfl(d.x), dy = rfl(d.y);
   const int nv = (int)(dx & 63u) + 1, id = (int)((dx >> 6) & 0x3FFFu) + lane, so = (int)(dx >> 20);
@@ -1336,12 +1358,17 @@ __device__ __forceinline__ int team_round(uint2 d, uint64_t hand8, const HT& hot
     const int mult = (int)((dy >> 12) & 3u);
     cat = (int)((dy >> 14) & 31u);
     const uint64_t unit = (cat == FOUR_TAKE_ONE || cat == FOUR_TAKE_TWO) ? 4ull : 3ull;  // main group: a quad, or `gap` triples
-    // c64[j]: the kicker positions of combination j as a nibble set over the REMAINS list (1 per kicker: g_c64); the
-    // main group's `gap` ranks are spliced in at nibble s_, `mult` cards per kicker (1 or 2: a shift)
-    const uint64_t c = c64[so + (in ? lane : 0)];
-    const uint64_t lowm = (1ull << (4 * s_)) - 1ull;
-    nib = (((unit * ONES) & ((1ull << (4 * gap)) - 1ull)) << (4 * s_)) + (((c & lowm) | ((c & ~lowm) << (4 * gap))) << (mult - 1));
-    (void)L;
+    nib = ((unit * ONES) & ((1ull << (4 * gap)) - 1ull)) << (4 * s_);
+    if constexpr (HT::HAS_C64) {
+      const uint64_t c = hot.c64[so + (in ? lane : 0)], lowm = (1ull << (4 * s_)) - 1ull;
+      nib += ((c & lowm) | ((c & ~lowm) << (4 * gap))) << (mult - 1);
+    } else {
+      const uint32_t e = hot.combo[so + (in ? lane : 0)];
+      for (int k = 0; k < L; ++k) {
+        const int pos = (int)((e >> (4 * k)) & 15u);
+        nib += (uint64_t)mult << (4 * (pos < s_ ? pos : pos + gap));
+      }
+    }
   } else {  // the joker-kicker extras (DDZ_NATIVE_JOKER_KICKERS builds): lanes 0..12 quad + jokers, 13..23 two triples + jokers
     const uint32_t quads = (dy >> 2) & 0x1FFFu, pairs3 = dy >> 15;
     const bool isq = lane < 13;
@@ -1431,7 +1458,7 @@ static_assert(SLAB_CH == 16, "four lanes per table of a chunk in the list search
 template <int MODE, bool IDS, bool COOP>
 __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   Stamps<12> stamps;
-  __shared__ HotTabT<false> hot;
+  __shared__ HotTabT<false, COOP && DDZ_HOT_C64 != 0> hot;  // (the nibble-set table where the block executes planned rounds)
   __shared__ uint4 s_chunk[WPB][SLAB_CH * DDZ_NFIELDS + SLAB_CH];  // per wave: the chunk's state rows + face side records
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
@@ -1450,7 +1477,6 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
   __shared__ int s_nheavy;
   __shared__ uint2 s_desc[COOP ? WPB : 1][TEAM_ROUNDS];     // per wave: the round records of its planned list (32 KB)
   __shared__ uint32_t s_tcnt[COOP ? WPB : 1][TEAM_ROUNDS];  // ... and the rounds' sizes, then sizes | bases << 16 (16 KB)
-  __shared__ uint64_t s_c64[COOP ? COMBO_WORDS : 1];        // the kicker combinations as nibble sets (team_round; 10.7 KB)
   __shared__ uint64_t s_keys[COOP ? WPB : 1][64];           // deal: the cards' keys (ranking by LDS broadcast reads)
   if (coop && threadIdx.x == 0) s_nheavy = 0;  // (in front of the first barrier)
   constexpr bool BYIDX = MODE == DDZ_STEP_CHOICE || MODE == STEP_Q;  // the move is an index into the current list
@@ -1512,11 +1538,8 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
       if (cnt_l < 0 || cnt_l > a.stride) cnt_l = 0;
     }
     // (one table per wave: wave 0 goes straight to the block's tables, the other fifteen fill the tables)
-    if (coop) { if (wv > 0) hot_fill<TB, HotTabT<false>, 64>(hot); }
+    if (coop) { if (wv > 0) hot_fill<TB, decltype(hot), 64>(hot); }
     else if (first) hot_fill<TB>(hot);
-    if (coop && wv > 0) {  // (while wave 0 decodes the block's tables)
-      for (int i = (int)threadIdx.x - 64; i < COMBO_WORDS; i += TB - 64) s_c64[i] = g_c64[i];
-    }
     uint32_t o_done = 0, o_illegal = 0, o_reward = 0;
     bool live = false;         // is there a list to write afterwards
     uint64_t qhand = 0;        // ... and for which (hand, combo to beat)
@@ -1798,7 +1821,7 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
             } else {
               const uint64_t hand8 = hand | 0x8888888888888888ull;
               for (int r = 0; r < R; ++r)
-                n += team_round<true, IDS>(s_desc[wv][r], hand8, hot, s_c64, lane, o.base + n, o.cap, a.rows, a.ids);
+                n += team_round<true, IDS>(s_desc[wv][r], hand8, hot, lane, o.base + n, o.cap, a.rows, a.ids);
               if (n > a.stride) {
                 if (lane == 0 && a.status) atomicOr(a.status, 2);
                 n = 0;
@@ -1823,7 +1846,7 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
           const uint64_t hand8 = ((uint64_t)rfl(e.x) | ((uint64_t)rfl(e.y) << 32)) | 0x8888888888888888ull;
           const int R = (int)rfl(e.z), ow = (int)rfl(e.w);
           for (int r = (wv + 5 * h) & (WPB - 1); r < R; r += WPB) {
-            const int k = team_round<false, IDS>(s_desc[ow][r], hand8, hot, s_c64, lane, 0, 0, a.rows, a.ids);
+            const int k = team_round<false, IDS>(s_desc[ow][r], hand8, hot, lane, 0, 0, a.rows, a.ids);
             if (lane == 0) s_tcnt[ow][r] = (uint32_t)k;
           }
         }
@@ -1858,7 +1881,7 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
           for (int r = (wv + 5 * h) & (WPB - 1); r < R; r += WPB) {
             const uint32_t cb = rfl(s_tcnt[ow][r]);
             if (cb & 0xFFFFu)  // (a round without a legal id -- most rounds of a kicker block -- is not repeated)
-              team_round<true, IDS>(s_desc[ow][r], hand8, hot, s_c64, lane, base + (int)(cb >> 16), base + a.stride, a.rows, a.ids);
+              team_round<true, IDS>(s_desc[ow][r], hand8, hot, lane, base + (int)(cb >> 16), base + a.stride, a.rows, a.ids);
           }
         }
       }
@@ -1933,7 +1956,7 @@ __global__ __launch_bounds__(TB, 4) void k_moves_slab(const uint4* __restrict__ 
                                                       int64_t n, int tpw, int32_t* __restrict__ counts,
                                                       uint4* __restrict__ rows, int32_t* __restrict__ ids, int64_t stride,
                                                       int32_t* __restrict__ status) {
-  __shared__ HotTabT<false> hot;
+  __shared__ HotTabL hot;
   const int lane = threadIdx.x & 63;
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * WPB + wv) * tpw;
@@ -2115,7 +2138,7 @@ __global__ __launch_bounds__(BLOCK) void k_moves(const uint4* __restrict__ hands
   const int wv = (int)rfl(threadIdx.x >> 6);
   const int64_t t0 = ((int64_t)blockIdx.x * MW + wv) * tpw;
   const int ntab = t0 < n ? (int)(n - t0 < tpw ? n - t0 : tpw) : 0;
-  __shared__ HotTab hot;
+  __shared__ HotTabT<true, DDZ_HOT_C64 != 0> hot;  // (nibble-set combinations: the stress set of plane-rich leads)
   int64_t base = 0;
   int cnt_l = 0, new_cnt_l = 0, part = 0, loc0 = 0;
   if (WRITE && ntab > 0) {

@@ -3,6 +3,8 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+if len(sys.argv) > 1:   # another engine build (A/B: tools/lib_ab_probe.py does the stepping kernels)
+    importlib.import_module("doudizhu-rl_amd._lib").use_library(os.path.abspath(sys.argv[1]))
 pkg = importlib.import_module("doudizhu-rl_amd")
 rng = np.random.default_rng(0)
 deck = np.repeat(np.arange(15), [4] * 13 + [1, 1])

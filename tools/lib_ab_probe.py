@@ -39,6 +39,20 @@ if __name__ == "__main__":
             st = env.stats()
             out.append(f"plies {st['plies']}")
             del env
+        # the stress set of bench.py (65,536 plane-rich 20-card leads) through get_moves_slab: the kicker-block rounds
+        import bench
+        hands = torch.from_numpy(bench.plane_rich_hands(65536, 12345)).cuda()
+        lasts = torch.zeros_like(hands)
+        o = pkg.get_moves_slab(hands, lasts, want_ids=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bs = 1e9
+        for _ in range(5):
+            e0.record()
+            for _ in range(20):
+                pkg.get_moves_slab(hands, lasts, want_ids=True, out=o)
+            e1.record(); torch.cuda.synchronize()
+            bs = min(bs, e0.elapsed_time(e1) / 20)
+        out.append(f"stress get_moves_slab: {bs * 1e3:6.1f} us (rows {int(o[0].sum())})")
         print(f"{os.path.basename(sys.argv[2]):28s} " + "; ".join(out), flush=True)
     else:
         for lib in (sys.argv[1:] or ["product"]):
