@@ -1902,7 +1902,12 @@ __global__ __launch_bounds__(TB, DDZ_SLAB_WAVES) void k_slab(SlabArgs a) {
         if (ew >> 31) {  // a finished game: the next episode's deal (native prepare(), spec v2), the lord leads
           const uint32_t ep = rfl(e.x);
           uint64_t h0, h1, h2;
+#ifdef DDZ_SLAB_DEAL_READLANE
           deal_wave(a.gid_base + (uint64_t)tt, ep, a.k0, a.k1, lane, h0, h1, h2);
+#else
+          // (ranking through LDS: the wave's chunk rows are dead here -- stored back before the items were published)
+          deal_wave_lds(a.gid_base + (uint64_t)tt, ep, a.k0, a.k1, lane, (uint64_t*)srow, h0, h1, h2);
+#endif
           if (lane < DDZ_NFIELDS)
             ((uint4*)(a.state + tt * STATE_ROW_BYTES))[lane] =
                 lane == 0 ? unpack_row(h0, 17) : lane == 1 ? unpack_row(h1, 20) : lane == 2 ? unpack_row(h2, 17)
