@@ -430,9 +430,15 @@ def dqn_leg(pkg, torch, dev, env):
             flop_total += st["flop"]
         elif st.get("bytes"):
             blocks[name] = hbm_block(st["kernel"], st["bytes"], st["us"] * 1e-6, note=st.get("note", ""))
+    dense_flop = 2.0 * T * (6 * 60 + 15 * 256) * 256 + sum(st["flop"] for k, st in stages.items() if k == "fc1_rows")
     res["roofline"] = mfma_block("the whole iteration (all launches)", flop_total, per_iter,
-                                 note="network FLOP of one iteration (first layer + fc1, fp32) / the iteration's wall time; "
-                                      "stages: per-kernel blocks", stages=blocks)
+                                 note="GEMM FLOP EXECUTED in one iteration / the iteration's wall time.  With shared rows (one row "
+                                      "per distinct (rank, face column) of the batch) the count-0 term needs ~20 x fewer FLOP than its "
+                                      "dense form (dense_form_flop: [T, 3840] x [3840, 256] over every table), so the matrix share of "
+                                      "the iteration is small and the fraction of the MFMA peak says little: the iteration is bound by "
+                                      "its HBM / latency stages (stages: per-kernel blocks)",
+                                 stages=blocks, executed_flop=flop_total, dense_form_flop=dense_flop,
+                                 dense_form_equivalent_TFLOPs=dense_flop / per_iter / 1e12)
     if hasattr(loop, "variants"):
         res["variants"] = loop.variants(timed_loop, sync)
     del loop, net

@@ -3628,7 +3628,7 @@ int ddz_q_need(ddz_env_t* e, const int32_t* counts, const int8_t* rows, int64_t 
 
 int ddz_q_features_needed(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
                           const float* acnt, const int32_t* row_index, float* y0, float* dy, int64_t row_capacity, void* stream) {
-  if (!face || !wf || !bias || !acnt || !row_index || !y0 || !dy || n_tables <= 0) return DDZ_EINVAL;
+  if (!face || !wf || !bias || !acnt || !row_index || !dy || n_tables <= 0) return DDZ_EINVAL;   // (y0 may be null: section 5)
   if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(row_index, 16) || !al(y0, 4) || !al(dy, 4)) return DDZ_EINVAL;
   if (row_capacity < 1 || row_capacity > (((int64_t)1 << 31) - 1) / QH || n_tables > ((int64_t)1 << 30)) return DDZ_ECAP;
   DeviceGuard g(device);
@@ -3659,13 +3659,107 @@ int ddz_q_fc1_dense(int device, const float* a, int64_t n_rows, int64_t k, const
 
 int ddz_q_fc1_rows(int device, const float* dy, const int32_t* seg, const uint8_t* row_cnt, const float* w2, const float* z, float* d,
                    int64_t row_capacity, void* stream) {
-  if (!dy || !seg || !w2 || !d || !z || !row_cnt) return DDZ_EINVAL;
+  if (!dy || !seg || !w2 || !d || ((z == nullptr) != (row_cnt == nullptr))) return DDZ_EINVAL;   // (z and row_cnt both null: no fold)
   if (!al(dy, 16) || !al(w2, 16) || !al(d, 4) || !al(seg, 4) || !al(z, 4)) return DDZ_EINVAL;
   if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
   DeviceGuard g(device);
   if (!g.ok) return DDZ_ENODEV;
   hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, dy, (int64_t)QH, w2, d,
                      (int64_t)0, QH, seg, z, row_cnt);
+  return check_launch();
+}
+
+// the shared-rows form of H0 (ddz_qnet.h section 5)
+int64_t ddz_q_shared_ws_bytes(void) { return (int64_t)QSH_WS_INTS * 4; }
+int ddz_q_shared_rows(ddz_env_t* e, void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* rows, int32_t* rep, int32_t* seg,
+                      void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!ws || !rows || !rep || !seg || !al(ws, 16) || !al(rows, 16) || !al(rep, 4) || !al(seg, 4)) return DDZ_EINVAL;
+  if (ws_bytes < ddz_q_shared_ws_bytes() || row_capacity % FC_M || e->T > ((int64_t)1 << 26)) return DDZ_ECAP;
+  const int64_t most = e->T * 15 < (int64_t)QSH_KEYS ? e->T * 15 : (int64_t)QSH_KEYS;   // distinct (rank, column) pairs at most
+  if (row_capacity < most + 15 * FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* slots = (int32_t*)ws;
+  int32_t* cnt = slots + QSH_KEYS;
+  int32_t* base = cnt + 15 * QSH_CPR;
+  if (hipMemsetAsync(slots, 0, (size_t)QSH_KEYS * 4, st) != hipSuccess) return DDZ_EHIP;
+  if (hipMemsetAsync(rep, 0xFF, (size_t)row_capacity * 4, st) != hipSuccess) return DDZ_EHIP;
+  const unsigned nb = (unsigned)((e->T * 16 + 255) / 256);
+  hipLaunchKernelGGL(k_qs_mark, dim3(nb), dim3(256), 0, st, (const uint8_t*)e->state, e->T, slots, rows);
+  hipLaunchKernelGGL(k_qs_count, dim3(15 * QSH_CPR), dim3(256), 0, st, (const int32_t*)slots, cnt);
+  hipLaunchKernelGGL(k_qs_seg, dim3(1), dim3(64), 0, st, (const int32_t*)cnt, base, seg, (int32_t)row_capacity);
+  hipLaunchKernelGGL(k_qs_assign, dim3(15 * QSH_CPR), dim3(256), 0, st, slots, (const int32_t*)base, rep, (int32_t)row_capacity);
+  hipLaunchKernelGGL(k_qs_rows, dim3(nb), dim3(256), 0, st, (const int32_t*)slots, e->T, rows);
+  return check_launch();
+}
+int ddz_q_features_rows(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, void* stream) {
+  if (!face || !wf || !bias || !rep || !seg || !ys || n_tables <= 0) return DDZ_EINVAL;
+  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(rep, 4) || !al(seg, 4) || !al(ys, 4)) return DDZ_EINVAL;
+  if (row_capacity < QR_TILE || row_capacity % QR_TILE || row_capacity > (((int64_t)1 << 31) - 1) / QH || n_tables > ((int64_t)1 << 26))
+    return DDZ_ECAP;
+  if (planes != 6) return DDZ_EINVAL;   // EnvCooperationSimplify's six planes: the only face whose columns ddz_q_shared_rows keys
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_q_feat_rows<6>, dim3((unsigned)(row_capacity / QR_TILE)), dim3(QH), 0, (hipStream_t)stream, (const float4*)face,
+                     n_tables, wf, bias, rep, seg, ys);
+  return check_launch();
+}
+// the needed rows D shared as well (ddz_qnet.h section 6)
+int64_t ddz_q_shared_need_ws_bytes(int64_t shared_row_capacity) {
+  if (shared_row_capacity <= 0 || shared_row_capacity % FC_M) return DDZ_EINVAL;
+  return (shared_row_capacity * 4 + 2 * (shared_row_capacity / FC_M)) * 4;   // dslot | cnt[tiles] | base[tiles]
+}
+int ddz_q_shared_need(ddz_env_t* e, const int32_t* row_index, const int32_t* rows, const int32_t* sseg, int64_t shared_row_capacity,
+                      void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* row_index2, int32_t* drep, int32_t* dseg,
+                      uint8_t* row_cnt, void* stream) {
+  if (!good(e)) return DDZ_EHANDLE;
+  if (!row_index || !rows || !sseg || !ws || !row_index2 || !drep || !dseg || !row_cnt) return DDZ_EINVAL;
+  if (!al(row_index, 4) || !al(rows, 4) || !al(sseg, 4) || !al(ws, 16) || !al(row_index2, 4) || !al(drep, 4) || !al(dseg, 4)) return DDZ_EINVAL;
+  if (shared_row_capacity <= 0 || shared_row_capacity % FC_M || shared_row_capacity > ((int64_t)1 << 28)) return DDZ_ECAP;
+  if (ws_bytes < ddz_q_shared_need_ws_bytes(shared_row_capacity)) return DDZ_ECAP;
+  if (row_capacity < 15 * FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_ECAP;
+  DeviceGuard g(e->device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* dslot = (int32_t*)ws;
+  const int64_t tiles = shared_row_capacity / FC_M;
+  int32_t* cnt = dslot + shared_row_capacity * 4;
+  int32_t* base = cnt + tiles;
+  if (hipMemsetAsync(dslot, 0, (size_t)shared_row_capacity * 16, st) != hipSuccess) return DDZ_EHIP;
+  if (hipMemsetAsync(drep, 0xFF, (size_t)row_capacity * 4, st) != hipSuccess) return DDZ_EHIP;
+  const unsigned nb = (unsigned)((e->T * QP_COLS + 255) / 256);
+  hipLaunchKernelGGL(k_qd_mark, dim3(nb), dim3(256), 0, st, row_index, rows, e->T, dslot, shared_row_capacity);
+  hipLaunchKernelGGL(k_qd_count, dim3((unsigned)tiles), dim3(256), 0, st, (const int32_t*)dslot, sseg, cnt);
+  hipLaunchKernelGGL(k_qd_seg, dim3(1), dim3(64), 0, st, (const int32_t*)cnt, sseg, base, dseg, (int32_t)row_capacity, e->sc.status);
+  hipLaunchKernelGGL(k_qd_assign, dim3((unsigned)tiles), dim3(256), 0, st, dslot, sseg, (const int32_t*)base, drep, row_cnt,
+                     (int32_t)row_capacity);
+  hipLaunchKernelGGL(k_qd_remap, dim3(nb), dim3(256), 0, st, row_index, rows, e->T, (const int32_t*)dslot, shared_row_capacity, row_index2);
+  return check_launch();
+}
+int ddz_q_features_drows(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                         const float* acnt, const int32_t* rep, int64_t shared_row_capacity, const int32_t* drep, const int32_t* dseg,
+                         float* dy, int64_t row_capacity, void* stream) {
+  if (!face || !wf || !bias || !acnt || !rep || !drep || !dseg || !dy || n_tables <= 0 || shared_row_capacity <= 0) return DDZ_EINVAL;
+  if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(acnt, 4) || !al(rep, 4) || !al(drep, 4) || !al(dseg, 4) || !al(dy, 4)) return DDZ_EINVAL;
+  if (row_capacity < QR_TILE || row_capacity % QR_TILE || row_capacity > (((int64_t)1 << 31) - 1) / QH || n_tables > ((int64_t)1 << 26))
+    return DDZ_ECAP;
+  if (planes != 6) return DDZ_EINVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_q_feat_drows<6>, dim3((unsigned)(row_capacity / QR_TILE)), dim3(QH), 0, (hipStream_t)stream, (const float4*)face,
+                     n_tables, wf, bias, acnt, rep, shared_row_capacity, drep, dseg, dy);
+  return check_launch();
+}
+int ddz_q_gather_h0(int device, const float* g, int64_t g_rows, const int32_t* rows, int64_t n_tables, float* h0, void* stream) {
+  if (!g || !rows || !h0 || n_tables <= 0 || g_rows <= 0) return DDZ_EINVAL;
+  if (!al(g, 16) || !al(rows, 16) || !al(h0, 16)) return DDZ_EINVAL;
+  DeviceGuard gd(device);
+  if (!gd.ok) return DDZ_ENODEV;
+  hipLaunchKernelGGL(k_qs_gather, dim3((unsigned)((n_tables + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, g_rows,
+                     rows, n_tables, (float4*)h0);
   return check_launch();
 }
 

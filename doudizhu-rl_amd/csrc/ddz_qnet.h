@@ -263,6 +263,12 @@ __global__ __launch_bounds__(QH) void k_q_feat_needed(   // ((QH, 5): 96 VGPRs +
     float* d0 = y0 + (tb + ti) * (15 * QH) + c;
 #pragma unroll 3
     for (int r = 0; r < 15; ++r) {   // (three ranks per trip: their LDS broadcasts and FMA chains interleave)
+      int4 pr4 = make_int4(-1, -1, -1, -1);
+      if (r < 13) pr4 = *(const int4*)&s_pidx[ti * QP_COLS + 4 * r];
+      else pr4.x = s_pidx[ti * QP_COLS + 52 + (r - 13)];
+      // y0 == null (the shared-rows form, section 5: the count-0 rows come from k_q_feat_rows): only the ranks some legal move
+      // takes cards of are evaluated (block-uniform: every thread of the block looks at the same table and rank)
+      if (!y0 && (pr4.x & pr4.y & pr4.z & pr4.w) == -1) continue;
       float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -273,10 +279,7 @@ __global__ __launch_bounds__(QH) void k_q_feat_needed(   // ((QH, 5): 96 VGPRs +
         s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
       }
       const float v0 = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      d0[r * QH] = v0;
-      int4 pr4 = make_int4(-1, -1, -1, -1);
-      if (r < 13) pr4 = *(const int4*)&s_pidx[ti * QP_COLS + 4 * r];
-      else pr4.x = s_pidx[ti * QP_COLS + 52 + (r - 13)];
+      if (y0) d0[r * QH] = v0;
       // (unsigned compares: -1 and anything beyond the buffer are skipped alike; row_index is device data)
       if ((uint32_t)pr4.x < nr) dy[(uint32_t)pr4.x * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[0][0], s1 + a[0][1]), fmaxf(s2 + a[0][2], s3 + a[0][3])) - v0;
       if ((uint32_t)pr4.y < nr) dy[(uint32_t)pr4.y * (uint32_t)QH + c] = fmaxf(fmaxf(s0 + a[1][0], s1 + a[1][1]), fmaxf(s2 + a[1][2], s3 + a[1][3])) - v0;
@@ -600,5 +603,351 @@ __global__ __launch_bounds__(TB, 4) void k_q_slab_needed(const float4* __restric
     __syncthreads();
     q_slab_moves(D, rows + t * stride, q + t * stride, n, 4 * wv, 4 * WPB, myidx, needm, h0, w, bias, s_big, QS_BIG, lane, status);
     __syncthreads();                                     // (the cache is free for the next heavy table)
+  }
+}
+
+// ---- 5. the count-0 term H0 from SHARED rows (faces of EnvCooperationSimplify, envi.py:201-217) ------------------------------
+// H0[t] = tab[t] + sum_r Y[t][r][0] x fc1[r]  is a [T][3840] x [3840][256] product -- but Y[t][r][0] depends only on the face
+// COLUMN of rank r, and that column is a function of (hand_r, taken_r, b1_r, b2_r, n1, n2) alone (k_observe<3>: four thermometer
+// planes and the two prob planes  [known <= j < total] n / (n1 + n2)  with known = hand_r + taken_r).  Across the tables of a
+// batch the columns of a rank repeat: 65,536 tables hold 983,040 (table, rank) columns and ~5 % as many DISTINCT (rank, column)
+// pairs (measured mid-game under the greedy network; 9 % under the random policy).  So:
+//   one row per distinct (rank, column):  first layer (k_q_feat_rows) and  G[row] = Y[row] x fc1[rank]  (k_fc1<true>, rank
+//   segments as for the needed rows) over ~5 * 10^4 rows instead of the K = 3840 product over every table, and
+//   H0[t] = tab[t] + sum_r G[row(t, r)]   (k_qs_gather: fifteen 1-KB rows per table, summed in rank order).
+// Every table still gets its exact H0 every iteration from the current weights -- nothing is cached across calls; what is
+// removed is the recomputation of identical subexpressions (equal to the dense form up to fp32 summation order: fifteen K = 256
+// chains added in rank order instead of one K = 3840 chain; tests: 1e-5).
+// Rows are found by direct addressing: slot[key], key = rank * QSH_COLS + column code (4,134,375 int32 slots, 16.5 MB):
+//   k_qs_mark   every (table, rank) writes its instance number into its slot (any winner: equal keys <=> equal columns)
+//   k_qs_count / k_qs_seg / k_qs_assign   occupied slots per 2048-key chunk -> rank segments (starts multiples of the GEMM tile)
+//               and chunk bases -> row number of every occupied slot in KEY ORDER (deterministic), rep[row] = an instance
+//   k_qs_rows   rows[t][r] = slot[key(t, r)] - 1
+constexpr int QSH_COLS = 625 * 441;                              // (hand, taken, b1, b2) in 0..4 each x (n1, n2) in 0..20 each
+constexpr int QSH_KEYS = 15 * QSH_COLS;
+constexpr int QSH_CHUNK = 2048;                                  // keys per block of the count / assign kernels (8 per thread)
+constexpr int QSH_CPR = (QSH_COLS + QSH_CHUNK - 1) / QSH_CHUNK;     // chunks per rank (135): a chunk never straddles two ranks
+constexpr int QSH_WS_INTS = QSH_KEYS + 2 * 15 * QSH_CPR;           // workspace: slots | cnt[15][QSH_CPR] | base[15][QSH_CPR]
+
+__global__ __launch_bounds__(256) void k_qs_mark(const uint8_t* __restrict__ state, int64_t T, int32_t* __restrict__ slots,
+                                                 int32_t* __restrict__ rows) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * 16) return;
+  const int64_t t = idx >> 4;
+  const int r = (int)(idx & 15);
+  if (r == 15) { rows[idx] = -1; return; }
+  const uint8_t* row = state + t * STATE_ROW_BYTES;
+  int role = row[DDZ_F_META * 16];
+  if (role > 2) role = 0;
+  const int rm1 = role == 0 ? 2 : role - 1, rp1 = role == 2 ? 0 : role + 1;
+  auto c4 = [](int v) { return v > 4 ? 4 : v; };   // (a thermometer saturates at 4; never index outside on a corrupted import)
+  const int hand = c4(row[(DDZ_F_HAND0 + role) * 16 + r]), taken = c4(row[DDZ_F_TAKEN * 16 + r]);
+  const int b1 = c4(row[(DDZ_F_RECENT0 + rm1) * 16 + r]), b2 = c4(row[(DDZ_F_RECENT0 + rp1) * 16 + r]);
+  int n1 = row[(DDZ_F_HAND0 + rp1) * 16 + 15], n2 = row[(DDZ_F_HAND0 + rm1) * 16 + 15];
+  n1 = n1 > 20 ? 20 : n1; n2 = n2 > 20 ? 20 : n2;
+  const int key = r * QSH_COLS + (((hand * 5 + taken) * 5 + b1) * 5 + b2) * 441 + n1 * 21 + n2;
+  slots[key] = (int32_t)idx + 1;
+  rows[idx] = key;
+}
+__global__ __launch_bounds__(256) void k_qs_count(const int32_t* __restrict__ slots, int32_t* __restrict__ cnt) {
+  __shared__ int s_n[4];
+  const int r = blockIdx.x / QSH_CPR, ch = blockIdx.x % QSH_CPR;
+  const int k0 = ch * QSH_CHUNK + (int)threadIdx.x * 8;
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) n += (k0 + i < QSH_COLS && slots[r * QSH_COLS + k0 + i] != 0) ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+// one block: rank totals -> seg (the layout k_fc1<true> reads, QN_SEG_WORDS ints), chunk bases.  row_capacity >= 15 T + 15 tiles
+// always suffices (checked on the host), so nothing can overflow; seg[33] stays 0.
+__global__ __launch_bounds__(64) void k_qs_seg(const int32_t* __restrict__ cnt, int32_t* __restrict__ base, int32_t* __restrict__ seg,
+                                               int32_t row_capacity) {
+  __shared__ int s_tot[16], s_start[16];
+  const int r = threadIdx.x;
+  if (r < 15) {
+    int n = 0;
+    for (int c = 0; c < QSH_CPR; ++c) n += cnt[r * QSH_CPR + c];
+    s_tot[r] = n;
+  }
+  __syncthreads();
+  if (r == 0) {
+    int start = 0, need = 0;
+    for (int q = 0; q < 15; ++q) {
+      s_start[q] = start;
+      seg[q] = start; seg[16 + q] = start / FC_M;
+      start += (s_tot[q] + FC_M - 1) / FC_M * FC_M;
+      need += s_tot[q];
+    }
+    const int over = start > row_capacity ? 1 : 0;
+    if (over) start = row_capacity / FC_M * FC_M;
+    seg[15] = start; seg[31] = start / FC_M; seg[32] = need; seg[33] = over;
+  }
+  __syncthreads();
+  if (r < 15) {
+    int b = s_start[r];
+    for (int c = 0; c < QSH_CPR; ++c) { base[r * QSH_CPR + c] = b; b += cnt[r * QSH_CPR + c]; }
+  }
+}
+__global__ __launch_bounds__(256) void k_qs_assign(int32_t* __restrict__ slots, const int32_t* __restrict__ base,
+                                                   int32_t* __restrict__ rep, int32_t row_capacity) {
+  __shared__ int s_w[4];
+  const int r = blockIdx.x / QSH_CPR, ch = blockIdx.x % QSH_CPR;
+  const int k0 = ch * QSH_CHUNK + (int)threadIdx.x * 8;
+  int v[8], n = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = k0 + i < QSH_COLS ? slots[r * QSH_COLS + k0 + i] : 0; n += v[i] != 0; }
+  // exclusive scan of n over the block: inside the wave by DPP-free shuffles, across the four waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int off = base[blockIdx.x] + inc - n;
+  for (int w = 0; w < wv; ++w) off += s_w[w];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (v[i] != 0) {
+      if (off < row_capacity) { rep[off] = v[i] - 1; slots[r * QSH_COLS + k0 + i] = off + 1; }
+      else slots[r * QSH_COLS + k0 + i] = 0;    // (cannot happen with the documented capacity; never a row beyond it)
+      ++off;
+    }
+}
+__global__ __launch_bounds__(256) void k_qs_rows(const int32_t* __restrict__ slots, int64_t T, int32_t* __restrict__ rows) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * 16) return;
+  const int key = rows[idx];
+  if (key >= 0) rows[idx] = (key < QSH_KEYS ? slots[key] : 0) - 1;
+}
+
+// first layer of the distinct rows: ys[row][c] = Y[t][r][0][c] for (t, r) = rep[row] (padding rows of a segment: zeros);
+// 256 threads = 256 channels, a tile of QR_TILE rows per block, their face columns staged in LDS
+constexpr int QR_TILE = 64;
+template <int P>
+__global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
+                                                    const float* __restrict__ bias, const int32_t* __restrict__ rep,
+                                                    const int32_t* __restrict__ seg, float* __restrict__ ys) {
+  const int c = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * QR_TILE;
+  if (row0 >= seg[15]) return;
+  __shared__ float4 s_col[QR_TILE * P];
+  __shared__ int s_ok[QR_TILE];
+  for (int i = threadIdx.x; i < QR_TILE * P; i += QH) {
+    const int j = i / P, p = i - j * P;
+    const int inst = rep[row0 + j];
+    const int64_t t = inst >> 4;
+    const bool ok = inst >= 0 && t < T && (inst & 15) < 15;
+    s_col[i] = ok ? face[(t * P + p) * 15 + (inst & 15)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p == 0) s_ok[j] = ok ? 1 : 0;
+  }
+  float w[P][10];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j <= k; ++j) w[p][q++] = wf[(int64_t)(p * 4 + j) * (4 * QH) + k * QH + c];
+  }
+  float b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = bias[k * QH + c];
+  __syncthreads();
+#pragma unroll 4
+  for (int j = 0; j < QR_TILE; ++j) {
+    float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {   // (the same expression, in the same order, as k_q_feat_needed: bit-identical Y)
+      const float4 x = s_col[j * P + p];
+      s0 += w[p][0] * x.x;
+      s1 += w[p][1] * x.x + w[p][2] * x.y;
+      s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
+      s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+    }
+    ys[(row0 + j) * QH + c] = s_ok[j] ? fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)) : 0.f;
+  }
+}
+
+// H0[t] += sum_r G[rows[t][r]] in rank order; one wavefront per table, lane l owns hidden units 4 l .. 4 l + 3
+__global__ __launch_bounds__(256) void k_qs_gather(const float4* __restrict__ G, int64_t g_rows, const int32_t* __restrict__ rows,
+                                                   int64_t T, float4* __restrict__ h0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int mine = lane < 16 ? rows[t * 16 + lane] : -1;
+  float4 acc = h0[t * 64 + lane];
+  float4 g[15];
+#pragma unroll
+  for (int r = 0; r < 15; ++r) {
+    const int row = __builtin_amdgcn_readlane(mine, r);
+    g[r] = (row >= 0 && row < g_rows) ? G[(int64_t)row * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < 15; ++r) { acc.x += g[r].x; acc.y += g[r].y; acc.z += g[r].z; acc.w += g[r].w; }
+  h0[t * 64 + lane] = acc;
+}
+
+// ---- 6. the needed rows D, shared as well ---------------------------------------------------------------------------------------
+// D[(t, r, c)] = (Y[t][r][c] - Y[t][r][0]) x fc1[r] + z[r][c] depends on (rank, column, c) only: one D row per distinct
+// (shared row s of section 5, count c) that SOME table needs, instead of one per (table, rank, count):
+//   k_qd_mark    every needed (t, r, c) (ddz_q_need's row_index >= 0) marks slot 4 s + c - 1, s = rows[t][r]
+//   k_qd_count / k_qd_seg / k_qd_assign   marked slots per tile of 128 shared rows (a tile never straddles two ranks) -> rank
+//                segments of the D rows + tile bases -> D row of every marked slot in slot order, drep[drow] = its slot,
+//                row_cnt[drow] = c (k_fc1<true> folds z[rank][c])
+//   k_qd_remap   row_index2[t][col] = D row of (rows[t][r], c)       (what the row stage k_q_slab_needed indexes D with)
+//   k_q_feat_drows   dy[drow] = Y[c] - Y[0] of the slot's column (read at the shared row's representative)
+constexpr int QD_SLOTS_PER_TILE = 4 * FC_M;      // 512 slots per tile of shared rows: 256 threads x 2
+static_assert(QD_SLOTS_PER_TILE == 512, "k_qd_count / k_qd_assign take two slots per thread");
+__device__ __forceinline__ void qd_col(int col, int& r, int& c) {   // row_index column -> (rank, count)
+  r = col < 52 ? col >> 2 : 13 + (col - 52);
+  c = col < 52 ? (col & 3) + 1 : 1;
+}
+__global__ __launch_bounds__(256) void k_qd_mark(const int32_t* __restrict__ row_index, const int32_t* __restrict__ rows, int64_t T,
+                                                 int32_t* __restrict__ dslot, int64_t s_rows) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * QP_COLS) return;
+  const int col = (int)(idx & (QP_COLS - 1));
+  if (col >= 54 || row_index[idx] < 0) return;
+  int r, c;
+  qd_col(col, r, c);
+  const int s = rows[(idx >> 6) * 16 + r];
+  if (s >= 0 && s < s_rows) dslot[(int64_t)s * 4 + c - 1] = 1;
+}
+__global__ __launch_bounds__(256) void k_qd_count(const int32_t* __restrict__ dslot, const int32_t* __restrict__ sseg,
+                                                  int32_t* __restrict__ cnt) {
+  __shared__ int s_n[4];
+  if ((int)blockIdx.x >= sseg[31]) return;            // tiles of shared rows in use
+  const int64_t e0 = (int64_t)blockIdx.x * QD_SLOTS_PER_TILE + 2 * threadIdx.x;
+  int n = (dslot[e0] != 0) + (dslot[e0 + 1] != 0);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+// one block: thread r walks the tiles of rank r's shared-row segment (sseg[16 + r] .. sseg[16 + r + 1]): totals -> dseg, tile bases
+__global__ __launch_bounds__(64) void k_qd_seg(const int32_t* __restrict__ cnt, const int32_t* __restrict__ sseg, int32_t* __restrict__ base,
+                                               int32_t* __restrict__ dseg, int32_t row_capacity, int32_t* __restrict__ status) {
+  __shared__ int s_tot[16], s_start[16];
+  const int r = threadIdx.x;
+  const int t0 = r < 15 ? sseg[16 + r] : 0, t1 = r < 15 ? (r < 14 ? sseg[16 + r + 1] : sseg[31]) : 0;
+  if (r < 15) {
+    int n = 0;
+    for (int t = t0; t < t1; ++t) n += cnt[t];
+    s_tot[r] = n;
+  }
+  __syncthreads();
+  if (r == 0) {
+    int start = 0, need = 0;
+    for (int q = 0; q < 15; ++q) {
+      s_start[q] = start;
+      dseg[q] = start; dseg[16 + q] = start / FC_M;
+      start += (s_tot[q] + FC_M - 1) / FC_M * FC_M;
+      need += s_tot[q];
+    }
+    const int over = start > row_capacity ? 1 : 0;   // (cannot happen: distinct (row, count) pairs <= needed (t, r, c) triples)
+    if (over) { start = row_capacity / FC_M * FC_M; atomicOr(status, 2); }
+    dseg[15] = start; dseg[31] = start / FC_M; dseg[32] = need; dseg[33] = over;
+  }
+  __syncthreads();
+  if (r < 15) {
+    int b = s_start[r];
+    for (int t = t0; t < t1; ++t) { base[t] = b; b += cnt[t]; }
+  }
+}
+__global__ __launch_bounds__(256) void k_qd_assign(int32_t* __restrict__ dslot, const int32_t* __restrict__ sseg,
+                                                   const int32_t* __restrict__ base, int32_t* __restrict__ drep,
+                                                   uint8_t* __restrict__ row_cnt, int32_t row_capacity) {
+  __shared__ int s_w[4];
+  if ((int)blockIdx.x >= sseg[31]) return;
+  const int64_t e0 = (int64_t)blockIdx.x * QD_SLOTS_PER_TILE + 2 * threadIdx.x;
+  const int v0 = dslot[e0] != 0, v1 = dslot[e0 + 1] != 0, n = v0 + v1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  int off = base[blockIdx.x] + inc - n;
+  for (int w = 0; w < wv; ++w) off += s_w[w];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (i == 0 ? v0 : v1) {
+      if (off < row_capacity) { drep[off] = (int32_t)(e0 + i); row_cnt[off] = (uint8_t)(((e0 + i) & 3) + 1); dslot[e0 + i] = off + 1; }
+      else dslot[e0 + i] = 0;
+      ++off;
+    }
+}
+__global__ __launch_bounds__(256) void k_qd_remap(const int32_t* __restrict__ row_index, const int32_t* __restrict__ rows, int64_t T,
+                                                  const int32_t* __restrict__ dslot, int64_t s_rows, int32_t* __restrict__ row_index2) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * QP_COLS) return;
+  const int col = (int)(idx & (QP_COLS - 1));
+  int out = -1;
+  if (col < 54 && row_index[idx] >= 0) {
+    int r, c;
+    qd_col(col, r, c);
+    const int s = rows[(idx >> 6) * 16 + r];
+    if (s >= 0 && s < s_rows) out = dslot[(int64_t)s * 4 + c - 1] - 1;
+  }
+  row_index2[idx] = out;
+}
+// dy[drow][ch] = Y[c] - Y[0] of the column of shared row s = drep[drow] >> 2, c = (drep[drow] & 3) + 1 (padding rows: zeros)
+template <int P>
+__global__ __launch_bounds__(QH) void k_q_feat_drows(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
+                                                     const float* __restrict__ bias, const float* __restrict__ acnt,
+                                                     const int32_t* __restrict__ rep, int64_t s_rows, const int32_t* __restrict__ drep,
+                                                     const int32_t* __restrict__ dseg, float* __restrict__ dy) {
+  const int ch = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * QR_TILE;
+  if (row0 >= dseg[15]) return;
+  __shared__ float4 s_col[QR_TILE * P];
+  __shared__ int s_c[QR_TILE];                 // count of the row (0: padding)
+  for (int i = threadIdx.x; i < QR_TILE * P; i += QH) {
+    const int j = i / P, p = i - j * P;
+    const int e = drep[row0 + j];
+    const int64_t s = e >> 2;
+    const int inst = (e >= 0 && s < s_rows) ? rep[s] : -1;
+    const int64_t t = inst >> 4;
+    const bool ok = inst >= 0 && t < T && (inst & 15) < 15;
+    s_col[i] = ok ? face[(t * P + p) * 15 + (inst & 15)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p == 0) s_c[j] = ok ? (e & 3) + 1 : 0;
+  }
+  float w[P][10];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j <= k; ++j) w[p][q++] = wf[(int64_t)(p * 4 + j) * (4 * QH) + k * QH + ch];
+  }
+  float b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = bias[k * QH + ch];
+  __syncthreads();
+#pragma unroll 2
+  for (int j = 0; j < QR_TILE; ++j) {
+    float s0 = b[0], s1 = b[1], s2 = b[2], s3 = b[3];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {   // (the expression and order of k_q_feat_needed: bit-identical dY)
+      const float4 x = s_col[j * P + p];
+      s0 += w[p][0] * x.x;
+      s1 += w[p][1] * x.x + w[p][2] * x.y;
+      s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
+      s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
+    }
+    const float v0 = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+    const int c = s_c[j];                      // (block-uniform)
+    float out = 0.f;
+    if (c > 0) {
+      const float* a = acnt + (int64_t)(c * 4) * QH + ch;   // acnt[c][k][ch], c = 1..4
+      out = fmaxf(fmaxf(s0 + a[0], s1 + a[QH]), fmaxf(s2 + a[2 * QH], s3 + a[3 * QH])) - v0;
+    }
+    dy[(row0 + j) * QH + ch] = out;
   }
 }

@@ -373,18 +373,25 @@ class FactorisedQ:
 
     # ---- needed form: H0 per table from ONE dense GEMM + D only for the (rank, count) rows some legal move uses ----
     @torch.no_grad()
-    def needed(self, env, face, gemm="torch"):
+    def needed(self, env, face, gemm="torch", shared=False):
         """face f32 [T,P,15,4] of env's CURRENT states (its slab lists are read on the device) -> NeededU: h0 f32 [T,256],
         d f32 [rows,256], row_index int32 [T,64], seg int32 [40] (device).  Nothing crosses to the host; every launch is
         graph-capturable.  The rows GEMM (D = dY x fc1[rank], segment sizes in device memory) is always the engine's fp32
         MFMA kernel (ddz_q_fc1_rows: a library GEMM would need the sizes on the host).  The dense GEMM (a plain
         [T, 3840] x [3840, 256] product) is torch.addmm = hipBLASLt by default (gemm="torch": 148 TFLOP/s in the loop), or
         the same MFMA kernel (gemm="mfma", ddz_q_fc1_dense: 125 TFLOP/s; six geometries measured, tools/fc1_probe.py).
+        shared=True (faces of EnvCooperationSimplify only, P = 6, and `face` MUST be env's variant-3 face of its current
+        states -- the rows are keyed from env's state): the SHARED-ROWS form of H0 (csrc/ddz_qnet.h section 5) -- no dense GEMM:
+        one row per distinct (rank, face column) of the batch (~5 % of the 15 T columns at 65,536 tables), first layer +
+        k_fc1 rows GEMM over those, H0[t] = table term + the fifteen rows of table t; the first layer of the needed rows then
+        skips the ranks no legal move touches.  Same values up to fp32 summation order (tests: 1e-5).
         The result aliases this object's workspace: consume it before the next call."""
         from . import engine as E
         if self._ver != self._versions():
             self.refresh()
         T, P, H, H1 = face.shape[0], self.P, self.H, self.H1
+        if shared and P != 6:
+            raise ValueError("shared=True keys the columns of EnvCooperationSimplify's six planes (face variant 3) only")
         if tuple(face.shape[1:]) != (P, 15, 4) or T != env.T or not face.is_cuda:
             raise ValueError(f"face must be a device tensor [T,{P},15,4] of the environment's tables")
         key = ("needed", face.device, T)
@@ -392,7 +399,7 @@ class FactorisedQ:
             FC_TILE = fc_tile()
             cap = (20 * T + 15 * FC_TILE + FC_TILE - 1) // FC_TILE * FC_TILE   # a move takes at most what the actor holds: <= 20 cards
             dev = face.device
-            self._ws[key] = {"cap": cap, "y0": torch.zeros((T, 15 * H), dtype=torch.float32, device=dev),
+            self._ws[key] = {"cap": cap, "y0": None,
                              "dy": torch.zeros((cap, H), dtype=torch.float32, device=dev),
                              "d": torch.zeros((cap, H1), dtype=torch.float32, device=dev),
                              "h0": torch.zeros((T, H1), dtype=torch.float32, device=dev),
@@ -402,6 +409,41 @@ class FactorisedQ:
                              "scratch": torch.zeros(E.q_need_scratch_bytes(T), dtype=torch.uint8, device=dev)}
         w = self._ws[key]
         env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"])
+        if shared:
+            if "srows" not in w:
+                FC_TILE = fc_tile()
+                scap = (min(15 * T, 4134375) + 15 * FC_TILE + FC_TILE - 1) // FC_TILE * FC_TILE   # cannot overflow (ddz_env.h)
+                dev = face.device
+                w.update({"scap": scap, "sws": torch.zeros(E.q_shared_ws_bytes(), dtype=torch.uint8, device=dev),
+                          "srows": torch.full((T, 16), -1, dtype=torch.int32, device=dev),
+                          "srep": torch.full((scap,), -1, dtype=torch.int32, device=dev),
+                          "sseg": torch.zeros(40, dtype=torch.int32, device=dev),
+                          "ys": torch.zeros((scap, H), dtype=torch.float32, device=dev),
+                          "g": torch.zeros((scap, H1), dtype=torch.float32, device=dev)})
+                w["y0"] = None                                                     # (1 GB at 65,536 tables: not needed in this form)
+            env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"])
+            E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"])
+            torch.addmm(self.base, face.view(T, P * 60), self.Mz_f, out=w["h0"])  # the per-table term
+            E.q_fc1_rows(w["ys"], w["sseg"], None, self.W2, None, w["g"])         # G = Y x fc1[rank]
+            E.q_gather_h0(w["g"], w["srows"], w["h0"])                            # H0[t] += sum_r G[row(t, r)]
+            if shared == "all":      # the needed rows shared as well: one D row per distinct (shared row, count) (section 6)
+                if "dws" not in w:
+                    dev = face.device
+                    w.update({"dws": torch.zeros(E.q_shared_need_ws_bytes(w["scap"]), dtype=torch.uint8, device=dev),
+                              "row_index2": torch.full((T, 64), -1, dtype=torch.int32, device=dev),
+                              "drep": torch.full((w["cap"],), -1, dtype=torch.int32, device=dev),
+                              "dseg": torch.zeros(40, dtype=torch.int32, device=dev),
+                              "drow_cnt": torch.zeros(w["cap"], dtype=torch.uint8, device=dev)})
+                env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"], w["row_index2"], w["drep"],
+                                  w["dseg"], w["drow_cnt"])
+                E.q_features_drows(face, self.Wf, self.bias_f, self.A, w["srep"], w["drep"], w["dseg"], w["dy"])
+                E.q_fc1_rows(w["dy"], w["dseg"], w["drow_cnt"], self.W2, self.Z, w["d"])
+                return NeededU(w["h0"], w["d"], w["row_index2"], w["dseg"])
+            E.q_features_needed(face, self.Wf, self.bias_f, self.A, w["row_index"], None, w["dy"])
+            E.q_fc1_rows(w["dy"], w["seg"], w["row_cnt"], self.W2, self.Z, w["d"])
+            return NeededU(w["h0"], w["d"], w["row_index"], w["seg"])
+        if w["y0"] is None:
+            w["y0"] = torch.zeros((T, 15 * H), dtype=torch.float32, device=face.device)
         E.q_features_needed(face, self.Wf, self.bias_f, self.A, w["row_index"], w["y0"], w["dy"])
         torch.addmm(self.base, face.view(T, P * 60), self.Mz_f, out=w["h0"])      # the per-table term (K = 60 P: small)
         if gemm == "mfma":
@@ -582,7 +624,7 @@ class PolicyLoop:
     mode "packed": round 3's form (15 + cards-in-hand rows per table, fifteen library GEMMs, one 128-byte device -> host copy
         per iteration for their shapes); mode "full": all 69 rows per table, fixed shapes (packed=True / False select these)."""
 
-    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=None, mode=None, gemm="torch"):
+    def __init__(self, env, net, face_variant=3, epsilon=0.0, auto_reset=True, packed=None, mode=None, gemm="torch", shared=None):
         from .engine import FACE_PLANES
         if FACE_PLANES[face_variant] != net.planes:
             raise ValueError("the network's input planes do not match the face variant")
@@ -593,6 +635,13 @@ class PolicyLoop:
         self.env, self.fq = env, FactorisedQ(net)
         self.variant, self.epsilon, self.auto_reset = int(face_variant), float(epsilon), bool(auto_reset)
         self.mode, self.gemm = mode, gemm
+        # shared rows (FactorisedQ.needed(shared=True)): the default wherever it applies -- the needed form on
+        # EnvCooperationSimplify faces (variant 3), whose columns ddz_q_shared_rows keys from the environment's state
+        # (True: H0 from shared rows; "all": the needed rows D shared as well -- the default)
+        self.shared = ("all" if (mode == "needed" and int(face_variant) == 3) else False) if shared is None else \
+            ("all" if shared == "all" else bool(shared))
+        if self.shared and (mode != "needed" or int(face_variant) != 3):
+            raise ValueError("shared rows need mode 'needed' and face variant 3")
         T = env.T
         self.face = env.observe(self.variant)
         self.packed = mode == "packed"
@@ -603,6 +652,14 @@ class PolicyLoop:
             env.legal_slab()
 
     def describe(self):
+        if self.mode == "needed" and self.shared:
+            return ("ddz_q_need (the (rank, count) rows the legal moves use) + ddz_q_shared_rows (one row per DISTINCT (rank, face "
+                    "column) of the batch, direct-addressed, on the device) -> ddz_q_features_rows (first layer of the shared rows) + "
+                    "ddz_q_features_needed (dY of the needed rows) -> ddz_q_fc1_rows twice (G = Y x fc1[rank] over the shared rows, "
+                    "D = dY x fc1[rank] over the needed rows: k_fc1, segment tables in device memory) -> H0 = table term + "
+                    "ddz_q_gather_h0 (the fifteen shared rows of every table; no dense K = 3840 GEMM) -> ddz_q_slab_needed -> "
+                    "ddz_policy_step_slab(greedy, face): every legal action of every table gets its exact Q value each iteration "
+                    "from the current weights; nothing is kept between iterations, nothing crosses to the host")
         if self.mode == "needed":
             return ("ddz_q_need (the (rank, count) rows the legal moves use, on the device) -> ddz_q_features_needed (first "
                     "layer: y0 per table + dY per needed row) -> H0 = tab + y0 x Wd (K = 3840: "
@@ -618,7 +675,7 @@ class PolicyLoop:
     def q_values(self):
         """q [T, stride] of the current lists (valid in [:, :counts[t]])"""
         if self.mode == "needed":
-            return self.fq.q_slab(self.env, self.fq.needed(self.env, self.face, gemm=self.gemm), out=self.q)
+            return self.fq.q_slab(self.env, self.fq.needed(self.env, self.face, gemm=self.gemm, shared=self.shared), out=self.q)
         if self.mode == "packed":
             return self.fq.q_slab(self.env, self.fq.tables_packed(self.face, self.env.actor_hands()), out=self.q)
         self.fq.tables(self.face, out=self.U)
@@ -642,9 +699,10 @@ class PolicyLoop:
             raise ValueError("profile() describes the needed form")
         env, fq, T, P = self.env, self.fq, self.env.T, self.fq.P
         w = None
-        names = ("need", "features", "table_term", "fc1_dense", "fc1_rows", "row_stage", "env_step")
+        names = ("need", "shared_rows", "features_shared", "features", "table_term", "fc1_dense", "fc1_shared", "gather_h0", "shared_need",
+                 "fc1_rows", "row_stage", "env_step")
         ev = {k: [] for k in names}
-        rows_needed = rows_padded = moves = 0
+        rows_needed = rows_padded = moves = rows_shared = rows_shared_padded = rows_private = 0
 
         def timed(name, fn):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -657,22 +715,76 @@ class PolicyLoop:
         w = fq._ws[("needed", self.face.device, T)]
         for _ in range(int(n)):
             timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"]))
-            timed("features", lambda: E.q_features_needed(self.face, fq.Wf, fq.bias_f, fq.A, w["row_index"], w["y0"], w["dy"]))
-            timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
-            if self.gemm == "mfma":
-                timed("fc1_dense", lambda: E.q_fc1_dense(w["y0"], fq.Wd, w["h0"]))
+            if self.shared:
+                timed("shared_rows", lambda: env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"]))
+                timed("features_shared", lambda: E.q_features_rows(self.face, fq.Wf, fq.bias_f, w["srep"], w["sseg"], w["ys"]))
+                timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
+                timed("fc1_shared", lambda: E.q_fc1_rows(w["ys"], w["sseg"], None, fq.W2, None, w["g"]))
+                timed("gather_h0", lambda: E.q_gather_h0(w["g"], w["srows"], w["h0"]))
+                if self.shared == "all":
+                    timed("shared_need", lambda: env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"],
+                                                                   w["row_index2"], w["drep"], w["dseg"], w["drow_cnt"]))
+                    timed("features", lambda: E.q_features_drows(self.face, fq.Wf, fq.bias_f, fq.A, w["srep"], w["drep"], w["dseg"], w["dy"]))
+                else:
+                    timed("features", lambda: E.q_features_needed(self.face, fq.Wf, fq.bias_f, fq.A, w["row_index"], None, w["dy"]))
+                sseg = w["sseg"].cpu()
+                rows_shared += int(sseg[32]); rows_shared_padded += int(sseg[15])
             else:
-                timed("fc1_dense", lambda: w["h0"].addmm_(w["y0"], fq.Wd))
-            timed("fc1_rows", lambda: E.q_fc1_rows(w["dy"], w["seg"], w["row_cnt"], fq.W2, fq.Z, w["d"]))
-            timed("row_stage", lambda: env.q_slab_needed(w["h0"], w["d"], w["row_index"], fq.w2, fq.b2, out=self.q))
-            seg = w["seg"].cpu()
+                timed("features", lambda: E.q_features_needed(self.face, fq.Wf, fq.bias_f, fq.A, w["row_index"], w["y0"], w["dy"]))
+                timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
+                if self.gemm == "mfma":
+                    timed("fc1_dense", lambda: E.q_fc1_dense(w["y0"], fq.Wd, w["h0"]))
+                else:
+                    timed("fc1_dense", lambda: w["h0"].addmm_(w["y0"], fq.Wd))
+            all_ = self.shared == "all"
+            sg, rc, ri = (w["dseg"], w["drow_cnt"], w["row_index2"]) if all_ else (w["seg"], w["row_cnt"], w["row_index"])
+            timed("fc1_rows", lambda: E.q_fc1_rows(w["dy"], sg, rc, fq.W2, fq.Z, w["d"]))
+            timed("row_stage", lambda: env.q_slab_needed(w["h0"], w["d"], ri, fq.w2, fq.b2, out=self.q))
+            seg = sg.cpu()
+            if all_:
+                rows_private += int(w["seg"].cpu()[32])
             rows_needed += int(seg[32]); rows_padded += int(seg[15]); moves += int(env.counts.sum())
             timed("env_step", lambda: env.policy_step_slab(self.q, self.epsilon, face_variant=self.variant, face_out=self.face,
                                                            choice_out=self.choice, auto_reset=self.auto_reset))
         torch.cuda.synchronize(env.device)
-        us = {k: sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v) for k, v in ev.items()}
+        us = {k: sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v) for k, v in ev.items() if v}
         rn, rp, mv = rows_needed / n, rows_padded / n, moves / n
         H = fq.H
+        if self.shared:
+            rs, rsp = rows_shared / n, rows_shared_padded / n
+            return {
+                "need": {"us": us["need"], "kernel": "k_q_need_mask + k_q_need_scan + k_q_need_assign", "bytes": mv * 16 + T * (8 + 8 + 256),
+                         "note": "list rows read, need sets written and read, row_index written"},
+                "shared_rows": {"us": us["shared_rows"], "kernel": "memset + k_qs_mark + k_qs_count + k_qs_seg + k_qs_assign + k_qs_rows",
+                                "bytes": T * 176 + 3 * 4134375 * 4 + T * 16 * 4 * 3 + rs * 8,
+                                "note": f"one row per distinct (rank, face column): {rs:.0f} of the {15 * T} columns ({rs / (15 * T):.3f}); "
+                                        "state read, the 16.5-MB slot table cleared / counted / assigned, rows [T,16] written"},
+                "features_shared": {"us": us["features_shared"], "kernel": "k_q_feat_rows<6>", "bytes": rs * (P * 16 + H * 4),
+                                    "note": "first layer (count 0) of the shared rows"},
+                "table_term": {"us": us["table_term"], "kernel": "torch.addmm (hipBLASLt)", "flop": 2.0 * T * P * 60 * H,
+                               "note": "fc1 bias + the face part of conv_shunzi: [T, 60 P] x [60 P, 256]"},
+                "fc1_shared": {"us": us["fc1_shared"], "kernel": "k_fc1<true>", "flop": 2.0 * rs * H * H,
+                               "note": f"G = Y x fc1[rank] over the {rs:.0f} shared rows ({rsp:.0f} with the padding of the fifteen "
+                                       f"segments) -- the dense form of the same term is 2 x {T} x 3840 x 256 = {2.0 * T * 15 * H * H / 1e9:.0f} GFLOP"},
+                "gather_h0": {"us": us["gather_h0"], "kernel": "k_qs_gather", "bytes": T * (64 + 2 * H * 4) + rs * H * 4,
+                              "note": f"H0 read and written, rows [T,16] read, every row of G once ({rs * H * 4 / 1e6:.0f} MB: the fifteen "
+                                      f"1-KB reads per table -- {T * 15 * H * 4 / 1e9:.2f} GB -- are served by L2 / MALL)"},
+                **({"shared_need": {"us": us["shared_need"], "kernel": "memset + k_qd_mark + k_qd_count + k_qd_seg + k_qd_assign + k_qd_remap",
+                                    "bytes": T * 64 * 4 * 3 + T * 64 + rs * 16 * 3 + rn * 5,
+                                    "note": f"one D row per distinct (shared row, count) some table needs: {rn:.0f} rows for the "
+                                            f"{rows_private / n:.0f} needed (table, rank, count) triples ({rows_private / n / T:.2f} per table)"},
+                    "features": {"us": us["features"], "kernel": "k_q_feat_drows<6>", "bytes": rn * (P * 16 + H * 4 + 8),
+                                 "note": "dY of the shared D rows"}} if self.shared == "all" else
+                   {"features": {"us": us["features"], "kernel": f"k_q_feat_needed<{P}> (y0 = null)", "bytes": T * P * 240 + rn * H * 4 + T * 256,
+                                 "note": "face + row_index read, dY [needed rows, 256] written; ranks no legal move touches are skipped"}}),
+                "fc1_rows": {"us": us["fc1_rows"], "kernel": "k_fc1<true>", "flop": 2.0 * rn * H * H,
+                             "note": f"D = dY x fc1[rank]: {rn:.0f} rows per iteration ({rn / T:.2f} per table), {rp:.0f} computed "
+                                     "with the padding of the fifteen tile-aligned segments; FLOP of the rows"},
+                "row_stage": {"us": us["row_stage"], "kernel": "k_q_slab_needed", "bytes": T * H * 4 + rn * H * 4 + mv * 20,
+                              "note": "H0 + the D rows + the list rows read, q written"},
+                "env_step": {"us": us["env_step"], "kernel": "k_slab<4,true>", "bytes": T * (2 * 176 + P * 240 + 8) + mv * 24,
+                             "note": "arg-max over q, apply, new lists, new face"},
+            }
         return {
             "need": {"us": us["need"], "kernel": "k_q_need_mask + k_q_need_scan + k_q_need_assign", "bytes": mv * 16 + T * (8 + 8 + 256),
                      "note": "list rows read, need sets written and read, row_index written"},
@@ -697,7 +809,11 @@ class PolicyLoop:
         out = {}
         T = self.env.T
         other = "mfma" if self.gemm == "torch" else "torch"
-        for name, kw in (("needed_dense_gemm_by_" + ("k_fc1" if other == "mfma" else "hipblaslt"), {"mode": "needed", "gemm": other}),
+        forms = [("needed_dense_gemm_by_" + ("k_fc1" if other == "mfma" else "hipblaslt"), {"mode": "needed", "gemm": other, "shared": False})]
+        if self.shared:   # the dense form of H0 (round 4's first form: one K = 3840 GEMM over every table)
+            forms.insert(0, ("needed_dense_gemm_by_" + ("hipblaslt" if self.gemm == "torch" else "k_fc1"),
+                             {"mode": "needed", "gemm": self.gemm, "shared": False}))
+        for name, kw in (*forms,
                          ("packed_rows_round3", {"mode": "packed"}), ("fixed_shapes", {"mode": "full"})):
             loop = PolicyLoop(self.env, self.fq.net, face_variant=self.variant, epsilon=self.epsilon, **kw)
             loop.run(2)

@@ -329,6 +329,28 @@ class BatchedEnv:
         check(self.lib.ddz_q_need(self._h, self._pp["counts"], self._pp["rows"], self.slab_stride, int(row_capacity),
                                   _p(scratch), scratch.numel(), _p(row_index), _p(seg), _p(row_cnt), _stream(self.device)))
 
+    def q_shared_rows(self, ws, row_capacity, rows, rep, seg):
+        """ddz_q_shared_rows: one row per DISTINCT (rank, face column) of the CURRENT states (EnvCooperationSimplify faces):
+        rows int32 [T,16] (row of (t, r)), rep int32 [row_capacity] (row -> instance 16 t + r), seg int32 [40] (rank segments);
+        ws uint8 [q_shared_ws_bytes()].  Nothing crosses to the host."""
+        if (rows.dtype != torch.int32 or tuple(rows.shape) != (self.T, 16) or not rows.is_contiguous() or rep.dtype != torch.int32
+                or rep.numel() < int(row_capacity) or seg.dtype != torch.int32 or seg.numel() < 40 or ws.dtype != torch.uint8):
+            raise ValueError("rows must be int32 [T,16], rep int32 [row_capacity], seg int32 [40], ws uint8")
+        check(self.lib.ddz_q_shared_rows(self._h, _p(ws), ws.numel(), int(row_capacity), _p(rows), _p(rep), _p(seg),
+                                         _stream(self.device)))
+
+    def q_shared_need(self, row_index, rows, sseg, shared_row_capacity, ws, row_capacity, row_index2, drep, dseg, row_cnt):
+        """ddz_q_shared_need: one D row per distinct (shared row, count) some table needs: row_index2 int32 [T,64], drep int32
+        [row_capacity], dseg int32 [40], row_cnt uint8 [row_capacity] from q_need's row_index and q_shared_rows' rows / sseg."""
+        for x, shp in ((row_index, (self.T, 64)), (row_index2, (self.T, 64)), (rows, (self.T, 16))):
+            if x.dtype != torch.int32 or tuple(x.shape) != shp or not x.is_contiguous():
+                raise ValueError("row_index / row_index2 must be int32 [T,64], rows int32 [T,16]")
+        if (drep.dtype != torch.int32 or drep.numel() < int(row_capacity) or row_cnt.dtype != torch.uint8 or row_cnt.numel() < int(row_capacity)
+                or dseg.dtype != torch.int32 or dseg.numel() < 40 or sseg.dtype != torch.int32 or sseg.numel() < 40 or ws.dtype != torch.uint8):
+            raise ValueError("drep int32 [row_capacity], row_cnt uint8 [row_capacity], dseg / sseg int32 [40], ws uint8")
+        check(self.lib.ddz_q_shared_need(self._h, _p(row_index), _p(rows), _p(sseg), int(shared_row_capacity), _p(ws), ws.numel(),
+                                         int(row_capacity), _p(row_index2), _p(drep), _p(dseg), _p(row_cnt), _stream(self.device)))
+
     def q_slab_needed(self, h0, d, row_index, w2, b2, out=None):
         """ddz_q_slab_needed: q f32 [T, stride] of every legal move from h0 f32 [T,256], d f32 [rows,256] (with z folded in by
         q_fc1_rows), row_index."""
@@ -637,8 +659,8 @@ def q_features_needed(face, wf, bias, acnt, row_index, y0, dy):
     T, P = int(face.shape[0]), int(face.shape[1])
     if face.dtype != torch.float32 or tuple(face.shape[2:]) != (15, 4) or not face.is_contiguous():
         raise ValueError("face must be a contiguous float32 [T,P,15,4] tensor")
-    if y0.dtype != torch.float32 or tuple(y0.shape) != (T, 15 * 256) or not y0.is_contiguous() or y0.device != dev:
-        raise ValueError("y0 must be a contiguous float32 [T, 3840] tensor on the same device")
+    if y0 is not None and (y0.dtype != torch.float32 or tuple(y0.shape) != (T, 15 * 256) or not y0.is_contiguous() or y0.device != dev):
+        raise ValueError("y0 must be a contiguous float32 [T, 3840] tensor on the same device (or None: dy alone)")
     if dy.dtype != torch.float32 or dy.dim() != 2 or dy.shape[1] != 256 or not dy.is_contiguous() or dy.device != dev:
         raise ValueError("dy must be a contiguous float32 [rows, 256] tensor on the same device")
     if row_index.dtype != torch.int32 or tuple(row_index.shape) != (T, 64) or not row_index.is_contiguous() or row_index.device != dev:
@@ -673,11 +695,82 @@ def q_fc1_rows(dy, seg, row_cnt, w2, z, d):
             raise ValueError("dy / d [rows,256], w2 [15,256,256]: contiguous float32 tensors on one device")
     if seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
         raise ValueError("seg must be int32 [40] on the same device")
-    if (row_cnt.dtype != torch.uint8 or row_cnt.numel() < n or row_cnt.device != dev or z.dtype != torch.float32
-            or z.numel() != 75 * 256 or not z.is_contiguous() or z.device != dev):
+    if (row_cnt is None) != (z is None):
+        raise ValueError("row_cnt and z: both or neither")
+    if z is not None and (row_cnt.dtype != torch.uint8 or row_cnt.numel() < n or row_cnt.device != dev or z.dtype != torch.float32
+                          or z.numel() != 75 * 256 or not z.is_contiguous() or z.device != dev):
         raise ValueError("row_cnt must be uint8 [rows], z float32 [15,5,256], on the same device")
     check(L.ddz_q_fc1_rows(dev.index, _p(dy), _p(seg), _p(row_cnt), _p(w2), _p(z), _p(d), n, _stream(dev)))
     return d
+
+
+def q_shared_ws_bytes():
+    return int(_lib.lib().ddz_q_shared_ws_bytes())
+
+
+def q_features_rows(face, wf, bias, rep, seg, ys):
+    """ddz_q_features_rows: ys f32 [rows,256] = the first layer (count 0) of the face column of every shared row (rep: row ->
+    instance 16 t + r, from BatchedEnv.q_shared_rows); face f32 [T,6,15,4]."""
+    L = _lib.lib()
+    dev = _require_gpu(face.device)
+    T, P = int(face.shape[0]), int(face.shape[1])
+    if face.dtype != torch.float32 or tuple(face.shape[1:]) != (6, 15, 4) or not face.is_contiguous():
+        raise ValueError("face must be a contiguous float32 [T,6,15,4] tensor (EnvCooperationSimplify)")
+    n = int(ys.shape[0])
+    if ys.dtype != torch.float32 or ys.dim() != 2 or ys.shape[1] != 256 or not ys.is_contiguous() or ys.device != dev:
+        raise ValueError("ys must be a contiguous float32 [rows,256] tensor on the same device")
+    if rep.dtype != torch.int32 or rep.numel() < n or rep.device != dev or seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
+        raise ValueError("rep must be int32 [rows], seg int32 [40], on the same device")
+    for w, k in ((wf, P * 4 * 1024), (bias, 1024)):
+        if w.dtype != torch.float32 or w.numel() != k or not w.is_contiguous() or w.device != dev:
+            raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024]")
+    check(L.ddz_q_features_rows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(rep), _p(seg), _p(ys), n, _stream(dev)))
+    return ys
+
+
+def q_shared_need_ws_bytes(shared_row_capacity):
+    n = int(_lib.lib().ddz_q_shared_need_ws_bytes(int(shared_row_capacity)))
+    if n < 0:
+        raise ValueError("the shared row capacity must be a positive multiple of the fc1 tile")
+    return n
+
+
+def q_features_drows(face, wf, bias, acnt, rep, drep, dseg, dy):
+    """ddz_q_features_drows: dy f32 [rows,256] = Y[c] - Y[0] of the column of every shared D row (drep: D row -> 4 * shared row
+    + c - 1, rep: shared row -> instance; from BatchedEnv.q_shared_need / q_shared_rows); face f32 [T,6,15,4]."""
+    L = _lib.lib()
+    dev = _require_gpu(face.device)
+    T, P = int(face.shape[0]), int(face.shape[1])
+    if face.dtype != torch.float32 or tuple(face.shape[1:]) != (6, 15, 4) or not face.is_contiguous():
+        raise ValueError("face must be a contiguous float32 [T,6,15,4] tensor (EnvCooperationSimplify)")
+    n = int(dy.shape[0])
+    if dy.dtype != torch.float32 or dy.dim() != 2 or dy.shape[1] != 256 or not dy.is_contiguous() or dy.device != dev:
+        raise ValueError("dy must be a contiguous float32 [rows,256] tensor on the same device")
+    for x in (rep, drep, dseg):
+        if x.dtype != torch.int32 or x.device != dev or not x.is_contiguous():
+            raise ValueError("rep / drep / dseg must be contiguous int32 tensors on the same device")
+    if drep.numel() < n or dseg.numel() < 40:
+        raise ValueError("drep must hold a slot per row of dy, dseg 40 ints")
+    for w, k in ((wf, P * 4 * 1024), (bias, 1024), (acnt, 5 * 4 * 256)):
+        if w.dtype != torch.float32 or w.numel() != k or not w.is_contiguous() or w.device != dev:
+            raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024], acnt [5,4,256]")
+    check(L.ddz_q_features_drows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(acnt), _p(rep), rep.numel(), _p(drep), _p(dseg),
+                                 _p(dy), n, _stream(dev)))
+    return dy
+
+
+def q_gather_h0(g, rows, h0):
+    """ddz_q_gather_h0: h0 f32 [T,256] += sum_r g[rows[t, r]] (rank order); g f32 [g_rows,256], rows int32 [T,16]."""
+    L = _lib.lib()
+    dev = _require_gpu(g.device)
+    T = int(h0.shape[0])
+    for x, shp in ((g, (int(g.shape[0]), 256)), (h0, (T, 256))):
+        if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != dev:
+            raise ValueError("g [g_rows,256], h0 [T,256]: contiguous float32 tensors on one device")
+    if rows.dtype != torch.int32 or tuple(rows.shape) != (T, 16) or not rows.is_contiguous() or rows.device != dev:
+        raise ValueError("rows must be a contiguous int32 [T,16] tensor on the same device")
+    check(L.ddz_q_gather_h0(dev.index, _p(g), int(g.shape[0]), _p(rows), T, _p(h0), _stream(dev)))
+    return h0
 
 
 def action_table(device="cuda:0", native_joker_kickers=False):

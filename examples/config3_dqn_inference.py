@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="needed", choices=("needed", "packed", "full"))
     ap.add_argument("--gemm", default="torch", choices=("mfma", "torch"), help="the plain dense GEMM: hipBLASLt (default) or the engine's k_fc1")
+    ap.add_argument("--dense", action="store_true", help="H0 by the dense K = 3840 GEMM over every table instead of the shared rows")
     ap.add_argument("--stages", action="store_true", help="also print the per-stage device times (HIP events)")
     a = ap.parse_args(argv)
     pkg = importlib.import_module("doudizhu-rl_amd")
@@ -37,7 +38,8 @@ def main(argv=None):
     T = a.tables
     env = pkg.BatchedEnv(T, seed=0, device=dev)
     env.reset()
-    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, mode=a.mode, gemm=a.gemm)
+    loop = glue.PolicyLoop(env, net, face_variant=3, epsilon=0.0, mode=a.mode, gemm=a.gemm,
+                           shared=False if (a.dense or a.mode != "needed") else None)
     loop.run(2)
     torch.cuda.synchronize()
     s0 = env.stats()

@@ -330,6 +330,46 @@ int ddz_q_slab_needed(ddz_env_t* env, const float* h0, const float* d, int64_t r
                       int64_t hidden, const float* w2, const float* b2, const int32_t* counts, const int8_t* rows,
                       int64_t stride, float* q, void* stream);
 
+/* H0 from SHARED rows (doudizhu-rl_amd/csrc/ddz_qnet.h section 5; the same forward, net.py:81-102, for faces of
+ * EnvCooperationSimplify, envi.py:201-217): Y[t][r][0] depends only on the face column of rank r, i.e. on (hand_r, taken_r,
+ * b1_r, b2_r, n1, n2), and across the tables of a batch those columns repeat (~5 % distinct at 65,536 tables).  One row per
+ * DISTINCT (rank, column): first layer + G[row] = Y[row] x fc1[rank] (ddz_q_fc1_rows with z = row_cnt = NULL), then
+ * H0[t] = table_term[t] + sum_r G[rows[t][r]] -- instead of the K = 15 * 256 dense product.  Exact per call (nothing is kept
+ * between calls), equal to the dense form up to fp32 summation order.
+ * ddz_q_shared_rows: from env's CURRENT state: rows int32 [T][16] (row of (t, r); column 15 = -1), rep int32 [row_capacity]
+ *   (row -> a (table, rank) instance 16 t + r that has this column; -1 = padding), seg int32 [40] as ddz_q_need's (rank
+ *   segments, starts multiples of the tile).  row_capacity: a multiple of the tile, >= min(15 T, 4134375) + 15 tiles (then
+ *   nothing can overflow).  ws: ddz_q_shared_ws_bytes() bytes (16.6 MB: one int32 slot per possible (rank, column)), 16-byte
+ *   aligned, contents irrelevant on entry.  Row numbers follow the key order: deterministic.
+ * ddz_q_features_rows: ys f32 [row_capacity][256] = first layer (count 0) of every row's column, read from `face` f32
+ *   [T][6][15][4] at rep[row]; padding rows = 0.  planes must be 6.
+ * ddz_q_gather_h0: h0 f32 [T][256] += sum over r = 0..14 (in this order) of g[rows[t][r]] (g f32 [g_rows][256]; rows < 0 or
+ *   >= g_rows contribute nothing).
+ * ddz_q_features_needed with y0 = NULL then evaluates only the ranks a legal move takes cards of (dy alone). */
+/* The needed rows shared as well (ddz_qnet.h section 6): D[(t, r, c)] depends on (rank, column, c) only -- one D row per
+ * distinct (shared row, count) some table needs.
+ * ddz_q_shared_need: row_index (ddz_q_need's: >= 0 <=> (t, r, c) is needed), rows / sseg (ddz_q_shared_rows') -> row_index2
+ *   int32 [T][64] (the D row of every needed (t, r, c); -1 otherwise: what ddz_q_slab_needed indexes d with), drep int32
+ *   [row_capacity] (D row -> 4 * shared row + c - 1; -1 = padding), dseg int32 [40] (rank segments of the D rows, as seg),
+ *   row_cnt uint8 [row_capacity] (c of every D row, for ddz_q_fc1_rows' z fold).  row_capacity as ddz_q_need's (distinct
+ *   pairs never outnumber the needed triples).  ws: ddz_q_shared_need_ws_bytes(shared_row_capacity) bytes, 16-byte aligned.
+ * ddz_q_features_drows: dy f32 [row_capacity][256] = Y[c] - Y[0] of every D row's column (face read at the shared row's
+ *   representative rep[]); padding rows = 0.  planes must be 6. */
+int64_t ddz_q_shared_need_ws_bytes(int64_t shared_row_capacity);
+int ddz_q_shared_need(ddz_env_t* env, const int32_t* row_index, const int32_t* rows, const int32_t* sseg,
+                      int64_t shared_row_capacity, void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* row_index2,
+                      int32_t* drep, int32_t* dseg, uint8_t* row_cnt, void* stream);
+int ddz_q_features_drows(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                         const float* acnt, const int32_t* rep, int64_t shared_row_capacity, const int32_t* drep,
+                         const int32_t* dseg, float* dy, int64_t row_capacity, void* stream);
+int64_t ddz_q_shared_ws_bytes(void);
+int ddz_q_shared_rows(ddz_env_t* env, void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* rows, int32_t* rep,
+                      int32_t* seg, void* stream);
+int ddz_q_features_rows(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
+                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, void* stream);
+int ddz_q_gather_h0(int device_id, const float* g, int64_t g_rows, const int32_t* rows, int64_t n_tables, float* h0,
+                    void* stream);
+
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
  * (rule_based/utils/card.py:34-159 order), device memory. */
 int ddz_action_table(int device_id, int8_t* rows, void* stream);

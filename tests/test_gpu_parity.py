@@ -1037,9 +1037,11 @@ def test_bench_contract():
     dq = legs["tables_65536_dqn_inference"]
     assert dq["roofline"]["bound"] == "mfma" and dq["roofline"]["dtype"] == "f32" and dq["env_steps_per_s"] > 5e6
     st = dq["roofline"]["stages"]
-    assert {"need", "features", "table_term", "fc1_dense", "fc1_rows", "row_stage", "env_step"} <= set(st)
-    assert st["fc1_dense"]["bound"] == "mfma" and st["fc1_rows"]["kernel"] == "k_fc1<true>" and st["features"]["bound"] == "hbm"
-    assert "needed_dense_gemm_by_k_fc1_env_steps_per_s" in dq["variants"]
+    assert {"need", "shared_rows", "features_shared", "features", "table_term", "fc1_shared", "gather_h0", "fc1_rows", "row_stage",
+            "env_step"} <= set(st)
+    assert st["fc1_shared"]["bound"] == "mfma" and st["fc1_rows"]["kernel"] == "k_fc1<true>" and st["features"]["bound"] == "hbm"
+    assert {"needed_dense_gemm_by_k_fc1_env_steps_per_s", "needed_dense_gemm_by_hipblaslt_env_steps_per_s"} <= set(dq["variants"])
+    assert dq["roofline"]["dense_form_flop"] > dq["roofline"]["executed_flop"] > 0
     assert abs(sum(dq["stages_us"].values()) - dq["us_per_iteration"]) < 0.25 * dq["us_per_iteration"]
     ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
     assert ret["up"] == ret["down"] == -ret["lord"] / 2 and ret["lord"] < -50  # rule farmers beat a random lord

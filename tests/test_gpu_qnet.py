@@ -108,6 +108,109 @@ def test_needed_rows_kernels_vs_torch_statement_and_literal_network(pkg, P, vari
     assert bool(torch.isfinite(qw[valid]).all()) and env.status() & 32
 
 
+@pytest.mark.parametrize("T", [700, 37, 5000])
+def test_shared_rows_form_of_h0_equals_the_dense_form(pkg, T):
+    """FactorisedQ.needed(shared=True) (csrc/ddz_qnet.h section 5: one row per distinct (rank, face column), no K = 3840
+    GEMM) against the dense form and the torch statement on fresh deals and mixed states: the row layout (every (t, r)
+    points at a row of ITS rank's segment whose representative has bit for bit the same face column; distinct columns have
+    distinct rows; padding rows are zero), H0 within 1e-5 (fp32 summation order), D bit for bit (the same kernel, y0 = null),
+    q within 1e-5 of the dense form and of the literal network."""
+    glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
+    torch.manual_seed(17)
+    net = glue.QNet(6).to(_dev()).eval()
+    net_cpu = copy.deepcopy(net).cpu()
+    env = pkg.BatchedEnv(T, seed=29, device=_dev())
+    env.reset()
+    fq, fq2, fq3 = glue.FactorisedQ(net), glue.FactorisedQ(net), glue.FactorisedQ(net)
+    for rounds in (0, 7, 30, 61):
+        env.rollout_random(rounds) if rounds else None
+        env.legal_slab()
+        face = env.observe(3)
+        dense = fq2.needed(env, face, gemm="torch")
+        nu = fq.needed(env, face, shared=True)
+        w = fq._ws[("needed", face.device, T)]
+        assert w["y0"] is None                                            # the [T, 3840] operand does not exist in this form
+        rows, rep, seg = w["srows"].cpu().long(), w["srep"].cpu().long(), w["sseg"].cpu().tolist()
+        assert seg[33] == 0 and seg[15] % glue.fc_tile() == 0 and seg[15] <= w["scap"]
+        assert bool((rows[:, 15] == -1).all())
+        cols = face.cpu().permute(0, 2, 1, 3).reshape(T * 15, 6, 4)       # column of instance 15 t + r
+        r15 = rows[:, :15]
+        for r in range(15):
+            lo, hi = seg[r], (seg[r + 1] if r < 14 else seg[15])
+            assert bool(((r15[:, r] >= lo) & (r15[:, r] < hi)).all())
+        inst = rep[r15]                                                   # [T,15] representative 16 t' + r'
+        assert bool((inst >= 0).all()) and bool(((inst & 15) == torch.arange(15)[None, :]).all())
+        rep_cols = cols[(inst >> 4) * 15 + (inst & 15)]
+        assert torch.equal(rep_cols, cols.view(T, 15, 6, 4))              # same column, bit for bit
+        # one row per distinct KEY (hand_r, taken_r, b1_r, b2_r, n1, n2) of a rank, numbered in key order; keys are at least as
+        # fine as columns (two keys may give one column: e.g. equal n1 / (n1 + n2)), never coarser (checked above)
+        st = env.state.cpu().view(T, 11, 16).long()
+        role = st[:, 10, 0]
+        ar = torch.arange(T)
+        rm1, rp1 = (role + 2) % 3, (role + 1) % 3
+        key = ((((st[ar, role, :15] * 5 + st[:, 9, :15]) * 5 + st[ar, 6 + rm1, :15]) * 5 + st[ar, 6 + rp1, :15]) * 441
+               + (st[ar, rp1, 15] * 21 + st[ar, rm1, 15])[:, None])
+        n_rows = 0
+        for r in range(15):
+            uk, inv = torch.unique(key[:, r], return_inverse=True)          # sorted: the row order inside the segment
+            assert torch.equal(r15[:, r], seg[r] + inv)
+            assert torch.unique(cols.view(T, 15, 24)[:, r], dim=0).shape[0] <= uk.numel()
+            n_rows += uk.numel()
+        assert seg[32] == n_rows
+        used = torch.zeros(w["scap"], dtype=torch.bool)
+        used[r15.reshape(-1)] = True
+        assert bool((rep[~used] == -1).all()) and float(w["ys"].cpu()[: seg[15]][~used[: seg[15]]].abs().max() if (~used[: seg[15]]).any() else 0.0) == 0.0
+        # values
+        assert float((nu.h0 - dense.h0).abs().max()) < 1e-5
+        ri = nu.row_index.cpu()
+        sel = ri[ri >= 0].long()
+        assert torch.equal(nu.row_index, dense.row_index) and torch.equal(nu.d.cpu()[sel], dense.d.cpu()[sel])
+        q = fq.q_slab(env, nu).clone()
+        q2 = fq2.q_slab(env, dense)
+        counts = env.counts.long()
+        valid = torch.arange(env.slab_stride, device=_dev())[None, :] < counts[:, None]
+        assert float((q[valid] - q2[valid]).abs().max()) < 1e-5
+        # the needed rows shared as well (section 6): one D row per distinct (shared row, count); the same D values bit for bit
+        # (the same expression per row, a k-ordered chain per row whatever its tile), hence bit-identical q
+        na = fq3.needed(env, face, shared="all")
+        w3 = fq3._ws[("needed", face.device, T)]
+        ri2, dseg, drep = na.row_index.cpu().long(), w3["dseg"].cpu().tolist(), w3["drep"].cpu().long()
+        assert torch.equal(ri2 >= 0, ri >= 0) and dseg[33] == 0 and dseg[15] % glue.fc_tile() == 0 and dseg[15] <= w3["cap"]
+        assert torch.equal(w3["srows"].cpu().long(), rows) and float((na.h0 - nu.h0).abs().max()) == 0.0
+        col = torch.arange(64)[None, :].expand(T, 64)
+        rk = torch.where(col < 52, col // 4, 13 + (col - 52).clamp(min=0))
+        cc = torch.where(col < 52, col % 4 + 1, torch.ones_like(col))
+        need = ri >= 0
+        slot = (rows.gather(1, rk.clamp(max=14)) * 4 + cc - 1)[need]       # 4 * shared row + c - 1 of every needed triple
+        assert torch.equal(drep[ri2[need]], slot)                          # its D row is the row of that slot ...
+        uq = torch.unique(slot)
+        assert dseg[32] == uq.numel()                                      # ... one row per distinct slot, in slot order per rank
+        assert torch.equal(torch.unique(ri2[need]), torch.sort(ri2[need].unique()).values) and torch.unique(ri2[need]).numel() == uq.numel()
+        assert torch.equal(w3["drow_cnt"].cpu().long()[ri2[need]], cc[need])
+        for r in range(15):
+            lo, hi = dseg[r], (dseg[r + 1] if r < 14 else dseg[15])
+            m = need & (rk == r)
+            assert bool(((ri2[m] >= lo) & (ri2[m] < hi)).all())
+        assert torch.equal(na.d.cpu()[ri2[need]], nu.d.cpu()[ri[need].long()])
+        q3 = fq3.q_slab(env, na)
+        assert torch.equal(q3[valid], q[valid])
+        off, lrows, n = _csr_of_slab(env)
+        seg_t = torch.repeat_interleave(torch.arange(T), counts.cpu())
+        pick = torch.arange(0, n, 7)
+        acts = (lrows.cpu()[pick, :15].float()[:, :, None] > torch.arange(4)[None, None, :]).float()
+        with torch.no_grad():
+            want = net_cpu(face.cpu()[seg_t[pick]], acts)[:, 0]
+        assert float((q[valid].cpu()[pick] - want).abs().max()) < 1e-5
+    assert env.status() == 0
+    # argument errors: a capacity that could overflow, a face with other planes
+    engine = importlib.import_module("doudizhu-rl_amd.engine")
+    with pytest.raises(pkg.DdzError):
+        env.q_shared_rows(w["sws"], glue.fc_tile() * 15, w["srows"], w["srep"][: glue.fc_tile() * 15], w["sseg"])
+    with pytest.raises(ValueError):
+        glue.FactorisedQ(glue.QNet(4).to(_dev()).eval()).needed(env, env.observe(0), shared=True)
+    assert engine is not None
+
+
 def test_need_capacity_overflow_is_flagged_not_written(pkg):
     """row_capacity too small for the needed rows: status bit 1, seg[33] = 1, the rows that do not fit are -1 (never an
     index beyond the capacity); a capacity that is no multiple of the fc1 tile is an argument error."""
@@ -142,15 +245,15 @@ def test_policy_loop_needed_form_is_graph_capturable(pkg):
     captured in a hipGraph and replayed 3 times == the same 18 iterations issued one by one (states, faces, choices and
     q values bit for bit), with either implementation of the dense GEMM."""
     glue = importlib.import_module("doudizhu-rl_amd.dqn_glue")
-    for gemm in ("mfma", "torch"):
+    for gemm, shared in (("mfma", False), ("torch", False), ("torch", True), ("torch", "all")):
         T, K = 1500, 6
         torch.manual_seed(1)
         net = glue.QNet(6).to(_dev()).eval()
         a = pkg.BatchedEnv(T, seed=21, device=_dev())
         b = pkg.BatchedEnv(T, seed=21, device=_dev())
         a.reset(); b.reset()
-        la = glue.PolicyLoop(a, net, face_variant=3, epsilon=0.1, gemm=gemm)
-        lb = glue.PolicyLoop(b, net, face_variant=3, epsilon=0.1, gemm=gemm)
+        la = glue.PolicyLoop(a, net, face_variant=3, epsilon=0.1, gemm=gemm, shared=shared)
+        lb = glue.PolicyLoop(b, net, face_variant=3, epsilon=0.1, gemm=gemm, shared=shared)
         la.run(2); lb.run(2)                                 # workspaces allocated, libraries warm
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
