@@ -378,7 +378,8 @@ __device__ __forceinline__ void fc1_chunk(const float* __restrict__ pa, const fl
 template <bool ROWS>
 __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                           float* __restrict__ C, int64_t M, int K, const int32_t* __restrict__ seg,
-                                                          const float* __restrict__ zfold, const uint8_t* __restrict__ row_cnt) {
+                                                          const float* __restrict__ zfold, const uint8_t* __restrict__ row_cnt,
+                                                          int accum = 0) {   // ROWS: accum != 0 adds the product to C (section 5)
   // ROWS with zfold / row_cnt: D[row] = dY[row] x fc1[rank] + z[rank][count of the row] -- the weights-only term of the action
   // plane rides on the row, so the row stage reads ONE 1-KB row per (move, rank) and keeps its LDS for the table's rows
   __shared__ float sA[2][FC_M * FC_AS];
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restr
       for (int j = 0; j < FC_TN; ++j) {
         const int col = 32 * FC_TN * wn + 32 * j + ccol;
         if (row < M)
-          C[row * FC_N + col] = ROWS ? (zoff >= 0 ? acc[i][j][g] + sZ[zoff + col] : acc[i][j][g]) : acc[i][j][g] + C[row * FC_N + col];
+          C[row * FC_N + col] = ROWS ? (zoff >= 0 ? acc[i][j][g] + sZ[zoff + col] : acc[i][j][g]) + (accum ? C[row * FC_N + col] : 0.f)
+                                     : acc[i][j][g] + C[row * FC_N + col];
       }
     }
 }
@@ -730,10 +732,23 @@ constexpr int QR_TILE = 64;
 template <int P>
 __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                     const float* __restrict__ bias, const int32_t* __restrict__ rep,
-                                                    const int32_t* __restrict__ seg, float* __restrict__ ys) {
+                                                    const int32_t* __restrict__ seg, float* __restrict__ ys,
+                                                    const float* __restrict__ mz, float* __restrict__ g) {
+  // mz / g (both or neither): the TABLE TERM folded into the rows -- the face part of conv_shunzi through fc1 is linear in the
+  // face, i.e. a sum over the ranks of (column of rank r) x mz[rows p * 60 + 4 r + w] (mz f32 [P * 60][256], the operand of the
+  // per-table GEMM [T, 60 P] x [60 P, 256] it replaces): g[row] = that product for the row's column and rank; the rows GEMM
+  // then ACCUMULATES into g, and H0[t] = base + sum_r g[row(t, r)].
   const int c = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * QR_TILE;
   if (row0 >= seg[15]) return;
+  int rk = 0;                       // the tile's rank (a 64-row tile never straddles two 128-aligned segments)
+#pragma unroll
+  for (int q = 1; q < 15; ++q) rk += row0 >= seg[q];
+  float m[P][4];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[p][k] = mz ? mz[(int64_t)(p * 60 + 4 * rk + k) * QH + c] : 0.f;
   __shared__ float4 s_col[QR_TILE * P];
   __shared__ int s_ok[QR_TILE];
   for (int i = threadIdx.x; i < QR_TILE * P; i += QH) {
@@ -769,17 +784,26 @@ __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ f
       s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
     }
     ys[(row0 + j) * QH + c] = s_ok[j] ? fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)) : 0.f;
+    if (g) {
+      float lin = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float4 x = s_col[j * P + p];
+        lin += m[p][0] * x.x + m[p][1] * x.y + m[p][2] * x.z + m[p][3] * x.w;
+      }
+      g[(row0 + j) * QH + c] = s_ok[j] ? lin : 0.f;
+    }
   }
 }
 
 // H0[t] += sum_r G[rows[t][r]] in rank order; one wavefront per table, lane l owns hidden units 4 l .. 4 l + 3
 __global__ __launch_bounds__(256) void k_qs_gather(const float4* __restrict__ G, int64_t g_rows, const int32_t* __restrict__ rows,
-                                                   int64_t T, float4* __restrict__ h0) {
+                                                   int64_t T, float4* __restrict__ h0, const float4* __restrict__ base) {
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
   const int mine = lane < 16 ? rows[t * 16 + lane] : -1;
-  float4 acc = h0[t * 64 + lane];
+  float4 acc = base ? base[lane] : h0[t * 64 + lane];   // (base f32 [256]: H0 = base + the rows; else H0 += the rows)
   float4 g[15];
 #pragma unroll
   for (int r = 0; r < 15; ++r) {

@@ -422,10 +422,10 @@ class FactorisedQ:
                           "g": torch.zeros((scap, H1), dtype=torch.float32, device=dev)})
                 w["y0"] = None                                                     # (1 GB at 65,536 tables: not needed in this form)
             env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"])
-            E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"])
-            torch.addmm(self.base, face.view(T, P * 60), self.Mz_f, out=w["h0"])  # the per-table term
-            E.q_fc1_rows(w["ys"], w["sseg"], None, self.W2, None, w["g"])         # G = Y x fc1[rank]
-            E.q_gather_h0(w["g"], w["srows"], w["h0"])                            # H0[t] += sum_r G[row(t, r)]
+            # G[row] = column x Mz[rank] (the table term is linear in the face: folded into the rows) + Y[row] x fc1[rank]
+            E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"], mz=self.Mz_f, g=w["g"])
+            E.q_fc1_rows_acc(w["ys"], w["sseg"], self.W2, w["g"])
+            E.q_gather_h0(w["g"], w["srows"], w["h0"], base=self.base)            # H0[t] = base + sum_r G[row(t, r)]
             if shared == "all":      # the needed rows shared as well: one D row per distinct (shared row, count) (section 6)
                 if "dws" not in w:
                     dev = face.device
@@ -717,10 +717,9 @@ class PolicyLoop:
             timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"]))
             if self.shared:
                 timed("shared_rows", lambda: env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"]))
-                timed("features_shared", lambda: E.q_features_rows(self.face, fq.Wf, fq.bias_f, w["srep"], w["sseg"], w["ys"]))
-                timed("table_term", lambda: torch.addmm(fq.base, self.face.view(T, P * 60), fq.Mz_f, out=w["h0"]))
-                timed("fc1_shared", lambda: E.q_fc1_rows(w["ys"], w["sseg"], None, fq.W2, None, w["g"]))
-                timed("gather_h0", lambda: E.q_gather_h0(w["g"], w["srows"], w["h0"]))
+                timed("features_shared", lambda: E.q_features_rows(self.face, fq.Wf, fq.bias_f, w["srep"], w["sseg"], w["ys"], mz=fq.Mz_f, g=w["g"]))
+                timed("fc1_shared", lambda: E.q_fc1_rows_acc(w["ys"], w["sseg"], fq.W2, w["g"]))
+                timed("gather_h0", lambda: E.q_gather_h0(w["g"], w["srows"], w["h0"], base=fq.base))
                 if self.shared == "all":
                     timed("shared_need", lambda: env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"],
                                                                    w["row_index2"], w["drep"], w["dseg"], w["drow_cnt"]))
@@ -759,10 +758,9 @@ class PolicyLoop:
                                 "bytes": T * 176 + 3 * 4134375 * 4 + T * 16 * 4 * 3 + rs * 8,
                                 "note": f"one row per distinct (rank, face column): {rs:.0f} of the {15 * T} columns ({rs / (15 * T):.3f}); "
                                         "state read, the 16.5-MB slot table cleared / counted / assigned, rows [T,16] written"},
-                "features_shared": {"us": us["features_shared"], "kernel": "k_q_feat_rows<6>", "bytes": rs * (P * 16 + H * 4),
-                                    "note": "first layer (count 0) of the shared rows"},
-                "table_term": {"us": us["table_term"], "kernel": "torch.addmm (hipBLASLt)", "flop": 2.0 * T * P * 60 * H,
-                               "note": "fc1 bias + the face part of conv_shunzi: [T, 60 P] x [60 P, 256]"},
+                "features_shared": {"us": us["features_shared"], "kernel": "k_q_feat_rows<6>", "bytes": rs * (P * 16 + 2 * H * 4),
+                                    "note": "first layer (count 0) of the shared rows + the table term of their columns (linear in the "
+                                            "face: folded into the rows -- no [T, 360] x [360, 256] GEMM per iteration)"},
                 "fc1_shared": {"us": us["fc1_shared"], "kernel": "k_fc1<true>", "flop": 2.0 * rs * H * H,
                                "note": f"G = Y x fc1[rank] over the {rs:.0f} shared rows ({rsp:.0f} with the padding of the fifteen "
                                        f"segments) -- the dense form of the same term is 2 x {T} x 3840 x 256 = {2.0 * T * 15 * H * H / 1e9:.0f} GFLOP"},

@@ -708,7 +708,7 @@ def q_shared_ws_bytes():
     return int(_lib.lib().ddz_q_shared_ws_bytes())
 
 
-def q_features_rows(face, wf, bias, rep, seg, ys):
+def q_features_rows(face, wf, bias, rep, seg, ys, mz=None, g=None):
     """ddz_q_features_rows: ys f32 [rows,256] = the first layer (count 0) of the face column of every shared row (rep: row ->
     instance 16 t + r, from BatchedEnv.q_shared_rows); face f32 [T,6,15,4]."""
     L = _lib.lib()
@@ -724,8 +724,27 @@ def q_features_rows(face, wf, bias, rep, seg, ys):
     for w, k in ((wf, P * 4 * 1024), (bias, 1024)):
         if w.dtype != torch.float32 or w.numel() != k or not w.is_contiguous() or w.device != dev:
             raise ValueError("weight tables must be contiguous float32 device tensors: wf [P*4,1024], bias [1024]")
-    check(L.ddz_q_features_rows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(rep), _p(seg), _p(ys), n, _stream(dev)))
+    if (mz is None) != (g is None):
+        raise ValueError("mz and g: both or neither")
+    if mz is not None and (mz.dtype != torch.float32 or tuple(mz.shape) != (P * 60, 256) or not mz.is_contiguous() or mz.device != dev
+                           or g.dtype != torch.float32 or tuple(g.shape) != (n, 256) or not g.is_contiguous() or g.device != dev):
+        raise ValueError("mz must be float32 [60 P, 256], g float32 [rows, 256], contiguous, on the same device")
+    check(L.ddz_q_features_rows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(rep), _p(seg), _p(ys), n, _p(mz), _p(g), _stream(dev)))
     return ys
+
+
+def q_fc1_rows_acc(y, seg, w2, g):
+    """ddz_q_fc1_rows_acc: g[row] += y[row] @ w2[rank of the row] for the rows / rank segments of seg (device int32 [40])."""
+    L = _lib.lib()
+    dev = _require_gpu(y.device)
+    n = int(y.shape[0])
+    for x, shp in ((y, (n, 256)), (g, (n, 256)), (w2, (15, 256, 256))):
+        if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != dev:
+            raise ValueError("y / g [rows,256], w2 [15,256,256]: contiguous float32 tensors on one device")
+    if seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
+        raise ValueError("seg must be int32 [40] on the same device")
+    check(L.ddz_q_fc1_rows_acc(dev.index, _p(y), _p(seg), _p(w2), _p(g), n, _stream(dev)))
+    return g
 
 
 def q_shared_need_ws_bytes(shared_row_capacity):
@@ -759,8 +778,9 @@ def q_features_drows(face, wf, bias, acnt, rep, drep, dseg, dy):
     return dy
 
 
-def q_gather_h0(g, rows, h0):
-    """ddz_q_gather_h0: h0 f32 [T,256] += sum_r g[rows[t, r]] (rank order); g f32 [g_rows,256], rows int32 [T,16]."""
+def q_gather_h0(g, rows, h0, base=None):
+    """ddz_q_gather_h0: h0 f32 [T,256] (+)= sum_r g[rows[t, r]] (rank order); g f32 [g_rows,256], rows int32 [T,16]; with
+    base f32 [256]: h0 = base + the sum."""
     L = _lib.lib()
     dev = _require_gpu(g.device)
     T = int(h0.shape[0])
@@ -769,7 +789,9 @@ def q_gather_h0(g, rows, h0):
             raise ValueError("g [g_rows,256], h0 [T,256]: contiguous float32 tensors on one device")
     if rows.dtype != torch.int32 or tuple(rows.shape) != (T, 16) or not rows.is_contiguous() or rows.device != dev:
         raise ValueError("rows must be a contiguous int32 [T,16] tensor on the same device")
-    check(L.ddz_q_gather_h0(dev.index, _p(g), int(g.shape[0]), _p(rows), T, _p(h0), _stream(dev)))
+    if base is not None and (base.dtype != torch.float32 or base.numel() != 256 or not base.is_contiguous() or base.device != dev):
+        raise ValueError("base must be a contiguous float32 [256] tensor on the same device")
+    check(L.ddz_q_gather_h0(dev.index, _p(g), int(g.shape[0]), _p(rows), T, _p(base), _p(h0), _stream(dev)))
     return h0
 
 

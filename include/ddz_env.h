@@ -366,9 +366,17 @@ int64_t ddz_q_shared_ws_bytes(void);
 int ddz_q_shared_rows(ddz_env_t* env, void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* rows, int32_t* rep,
                       int32_t* seg, void* stream);
 int ddz_q_features_rows(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
-                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, void* stream);
-int ddz_q_gather_h0(int device_id, const float* g, int64_t g_rows, const int32_t* rows, int64_t n_tables, float* h0,
-                    void* stream);
+                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, const float* mz, float* g,
+                        void* stream);
+int ddz_q_gather_h0(int device_id, const float* g, int64_t g_rows, const int32_t* rows, int64_t n_tables, const float* base,
+                    float* h0, void* stream);
+/* The table term folded into the rows: it is linear in the face (fc1 bias + the face part of conv_shunzi through fc1), i.e.
+ * base + sum_r column_r x mz[p * 60 + 4 r + w] (mz f32 [60 * 6][256]: the operand of the [T, 360] x [360, 256] GEMM it
+ * replaces).  ddz_q_features_rows with mz / g (both or neither) writes that product of every row's column into g
+ * f32 [row_capacity][256]; ddz_q_fc1_rows_acc: g[row] += y[row] x w2[rank]; ddz_q_gather_h0 with base f32 [256] (or NULL:
+ * h0 += ...): h0[t] = base + sum_r g[rows[t][r]]. */
+int ddz_q_fc1_rows_acc(int device_id, const float* y, const int32_t* seg, const float* w2, float* g, int64_t row_capacity,
+                       void* stream);
 
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
  * (rule_based/utils/card.py:34-159 order), device memory. */

@@ -1037,7 +1037,7 @@ def test_bench_contract():
     dq = legs["tables_65536_dqn_inference"]
     assert dq["roofline"]["bound"] == "mfma" and dq["roofline"]["dtype"] == "f32" and dq["env_steps_per_s"] > 5e6
     st = dq["roofline"]["stages"]
-    assert {"need", "shared_rows", "features_shared", "features", "table_term", "fc1_shared", "gather_h0", "fc1_rows", "row_stage",
+    assert {"need", "shared_rows", "features_shared", "features", "shared_need", "fc1_shared", "gather_h0", "fc1_rows", "row_stage",
             "env_step"} <= set(st)
     assert st["fc1_shared"]["bound"] == "mfma" and st["fc1_rows"]["kernel"] == "k_fc1<true>" and st["features"]["bound"] == "hbm"
     assert {"needed_dense_gemm_by_k_fc1_env_steps_per_s", "needed_dense_gemm_by_hipblaslt_env_steps_per_s"} <= set(dq["variants"])
