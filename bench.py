@@ -439,6 +439,15 @@ def dqn_leg(pkg, torch, dev, env):
                                       "its HBM / latency stages (stages: per-kernel blocks)",
                                  stages=blocks, executed_flop=flop_total, dense_form_flop=dense_flop,
                                  dense_form_equivalent_TFLOPs=dense_flop / per_iter / 1e12)
+    try:   # the same loop replayed from ONE hipGraph of 5 iterations (no host work between its ~150 launches)
+        g = loop.capture(5)
+        dtg, repg = timed_loop(g.replay, sync, min_s=0.3, max_reps=64)
+        res["graph_replay"] = {"env_steps_per_s": T * 5 * repg / dtg, "us_per_iteration": dtg / (5 * repg) * 1e6,
+                               "note": "PolicyLoop.capture(5): five iterations as one hipGraph, replayed; the headline of this leg is the "
+                                       "eager loop"}
+        del g
+    except Exception as e:  # noqa: BLE001
+        res["graph_replay"] = {"error": repr(e)}
     if hasattr(loop, "variants"):
         res["variants"] = loop.variants(timed_loop, sync)
     del loop, net

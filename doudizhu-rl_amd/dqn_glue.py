@@ -181,6 +181,7 @@ class FactorisedQ:
     (refresh() is called automatically when a parameter's version counter moved).  Eval semantics (no dropout)."""
     def __init__(self, net, chunk_tables=16384):
         self.net, self.chunk = net, int(chunk_tables)
+        self.two_streams = True        # needed(shared="all"): the D chain on a side stream beside the H0 chain
         # packed form: fifteen fc1 GEMMs over exactly the rows that exist (default), or ONE batched GEMM over segments
         # padded to the longest (True).  Measured at 65,536 tables: steady state (thousands of iterations in) 4.00 against
         # 4.23 ms per iteration; a batch of young games (30 iterations in, 16 % padding) 3.75 against 3.60 ms.
@@ -422,10 +423,13 @@ class FactorisedQ:
                           "g": torch.zeros((scap, H1), dtype=torch.float32, device=dev)})
                 w["y0"] = None                                                     # (1 GB at 65,536 tables: not needed in this form)
             env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"])
-            # G[row] = column x Mz[rank] (the table term is linear in the face: folded into the rows) + Y[row] x fc1[rank]
-            E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"], mz=self.Mz_f, g=w["g"])
-            E.q_fc1_rows_acc(w["ys"], w["sseg"], self.W2, w["g"])
-            E.q_gather_h0(w["g"], w["srows"], w["h0"], base=self.base)            # H0[t] = base + sum_r G[row(t, r)]
+
+            def h0_chain():
+                # G[row] = column x Mz[rank] (the table term is linear in the face: folded into the rows) + Y[row] x fc1[rank]
+                E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"], mz=self.Mz_f, g=w["g"])
+                E.q_fc1_rows_acc(w["ys"], w["sseg"], self.W2, w["g"])
+                E.q_gather_h0(w["g"], w["srows"], w["h0"], base=self.base)        # H0[t] = base + sum_r G[row(t, r)]
+
             if shared == "all":      # the needed rows shared as well: one D row per distinct (shared row, count) (section 6)
                 if "dws" not in w:
                     dev = face.device
@@ -433,12 +437,29 @@ class FactorisedQ:
                               "row_index2": torch.full((T, 64), -1, dtype=torch.int32, device=dev),
                               "drep": torch.full((w["cap"],), -1, dtype=torch.int32, device=dev),
                               "dseg": torch.zeros(40, dtype=torch.int32, device=dev),
-                              "drow_cnt": torch.zeros(w["cap"], dtype=torch.uint8, device=dev)})
-                env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"], w["row_index2"], w["drep"],
-                                  w["dseg"], w["drow_cnt"])
-                E.q_features_drows(face, self.Wf, self.bias_f, self.A, w["srep"], w["drep"], w["dseg"], w["dy"])
-                E.q_fc1_rows(w["dy"], w["dseg"], w["drow_cnt"], self.W2, self.Z, w["d"])
+                              "drow_cnt": torch.zeros(w["cap"], dtype=torch.uint8, device=dev),
+                              "side": torch.cuda.Stream(dev), "fork": torch.cuda.Event(), "join": torch.cuda.Event()})
+                # The H0 chain (first layer of the rows -> G -> gather) and the D chain (D rows -> dY -> D) share only their
+                # inputs: both GEMMs are a few hundred tiles -- one or two rounds over the 256 CUs, the launch as long as its
+                # last round -- and the bookkeeping kernels are latency-bound, so the D chain runs on a SIDE STREAM beside the
+                # H0 chain (fork / join by events: no host synchronisation, capturable in a hipGraph).
+                cur = torch.cuda.current_stream(face.device)
+                two = self.two_streams
+                if two:
+                    w["fork"].record(cur)
+                    w["side"].wait_event(w["fork"])
+                with torch.cuda.stream(w["side"] if two else cur):
+                    env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"], w["row_index2"], w["drep"],
+                                      w["dseg"], w["drow_cnt"])
+                    E.q_features_drows(face, self.Wf, self.bias_f, self.A, w["srep"], w["drep"], w["dseg"], w["dy"])
+                    E.q_fc1_rows(w["dy"], w["dseg"], w["drow_cnt"], self.W2, self.Z, w["d"])
+                    if two:
+                        w["join"].record(w["side"])
+                h0_chain()
+                if two:
+                    cur.wait_event(w["join"])
                 return NeededU(w["h0"], w["d"], w["row_index2"], w["dseg"])
+            h0_chain()
             E.q_features_needed(face, self.Wf, self.bias_f, self.A, w["row_index"], None, w["dy"])
             E.q_fc1_rows(w["dy"], w["seg"], w["row_cnt"], self.W2, self.Z, w["d"])
             return NeededU(w["h0"], w["d"], w["row_index"], w["seg"])
@@ -690,6 +711,25 @@ class PolicyLoop:
     def run(self, n):
         for _ in range(int(n)):
             self.step()
+
+    def capture(self, n=1):
+        """n lock-step iterations as ONE hipGraph (the needed forms have no host synchronisation and no size-dependent shape):
+        returns the torch.cuda.CUDAGraph; every .replay() runs the n iterations on the state the previous ones left (states,
+        faces, choices, q values: bit for bit what n eager step() calls give -- tests/test_gpu_qnet.py).  Call step() a few
+        times first (workspaces allocated, libraries warm).  An iteration is ~30 short launches: the replay removes the host's
+        share of the gaps between them."""
+        if self.mode != "needed":
+            raise ValueError("only the needed forms are free of host synchronisation")
+        dev = self.env.device
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                self.run(n)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        return g
 
     def profile(self, n=10):
         """Per-stage device time of n iterations of the needed form (HIP events on the launching stream around every stage)

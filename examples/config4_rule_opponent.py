@@ -51,7 +51,7 @@ def main():
         ragged forward of dqn_glue (per-rank GEMMs over the rows the actors' hands allow + ddz_q_slab_packed), arg-max by
         ddz_select_slab"""
         env.observe(3, out=face)
-        q = fq.q_slab(env, fq.needed(env, face), out=qbuf)
+        q = fq.q_slab(env, fq.needed(env, face, shared="all"), out=qbuf)   # (shared rows: csrc/ddz_qnet.h sections 5-6)
         choice = env.select_slab(q)
         return env.slab_ids().gather(1, choice.clamp(min=0).long()[:, None])[:, 0].to(torch.int32)
 

@@ -1042,7 +1042,8 @@ def test_bench_contract():
     assert st["fc1_shared"]["bound"] == "mfma" and st["fc1_rows"]["kernel"] == "k_fc1<true>" and st["features"]["bound"] == "hbm"
     assert {"needed_dense_gemm_by_k_fc1_env_steps_per_s", "needed_dense_gemm_by_hipblaslt_env_steps_per_s"} <= set(dq["variants"])
     assert dq["roofline"]["dense_form_flop"] > dq["roofline"]["executed_flop"] > 0
-    assert abs(sum(dq["stages_us"].values()) - dq["us_per_iteration"]) < 0.25 * dq["us_per_iteration"]
+    # (the stages are timed one after the other; in the loop the D chain runs on a side stream beside the H0 chain)
+    assert 0.6 * dq["us_per_iteration"] < sum(dq["stages_us"].values()) < 1.5 * dq["us_per_iteration"]
     ret = legs["tables_65536_rule_opponent"]["mean_episode_return"]
     assert ret["up"] == ret["down"] == -ret["lord"] / 2 and ret["lord"] < -50  # rule farmers beat a random lord
     c = j["cpu_baseline"]
