@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_qs_rows(const int32_t* __restrict__ slo
 
 // first layer of the distinct rows: ys[row][c] = Y[t][r][0][c] for (t, r) = rep[row] (padding rows of a segment: zeros);
 // 256 threads = 256 channels, a tile of QR_TILE rows per block, their face columns staged in LDS
-constexpr int QR_TILE = 64;
+constexpr int QR_TILE = 64;    // rows per block (128: fewer, longer blocks -- measured slower: 102 against 88 us for 7.3 * 10^4 rows)
 template <int P>
 __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                     const float* __restrict__ bias, const int32_t* __restrict__ rep,
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ f
   const int c = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * QR_TILE;
   if (row0 >= seg[15]) return;
-  int rk = 0;                       // the tile's rank (a 64-row tile never straddles two 128-aligned segments)
+  int rk = 0;                       // the tile's rank (a tile never straddles two 128-aligned segments)
 #pragma unroll
   for (int q = 1; q < 15; ++q) rk += row0 >= seg[q];
   float m[P][4];
@@ -825,6 +825,7 @@ __global__ __launch_bounds__(256) void k_qs_gather(const float4* __restrict__ G,
 //   k_qd_remap   row_index2[t][col] = D row of (rows[t][r], c)       (what the row stage k_q_slab_needed indexes D with)
 //   k_q_feat_drows   dy[drow] = Y[c] - Y[0] of the slot's column (read at the shared row's representative)
 constexpr int QD_SLOTS_PER_TILE = 4 * FC_M;      // 512 slots per tile of shared rows: 256 threads x 2
+static_assert(QR_TILE <= FC_M && FC_M % QR_TILE == 0, "a first-layer tile lies inside one rank segment");
 static_assert(QD_SLOTS_PER_TILE == 512, "k_qd_count / k_qd_assign take two slots per thread");
 __device__ __forceinline__ void qd_col(int col, int& r, int& c) {   // row_index column -> (rank, count)
   r = col < 52 ? col >> 2 : 13 + (col - 52);

@@ -409,7 +409,15 @@ class FactorisedQ:
                              "row_cnt": torch.zeros(cap, dtype=torch.uint8, device=dev),
                              "scratch": torch.zeros(E.q_need_scratch_bytes(T), dtype=torch.uint8, device=dev)}
         w = self._ws[key]
-        env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"])
+        early = shared == "all" and self.two_streams and "side" in w     # the need sets on the side stream, beside the shared rows
+        if early:
+            cur = torch.cuda.current_stream(face.device)
+            w["fork0"].record(cur)
+            w["side"].wait_event(w["fork0"])
+            with torch.cuda.stream(w["side"]):
+                env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"])
+        else:
+            env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"])
         if shared:
             if "srows" not in w:
                 FC_TILE = fc_tile()
@@ -438,7 +446,8 @@ class FactorisedQ:
                               "drep": torch.full((w["cap"],), -1, dtype=torch.int32, device=dev),
                               "dseg": torch.zeros(40, dtype=torch.int32, device=dev),
                               "drow_cnt": torch.zeros(w["cap"], dtype=torch.uint8, device=dev),
-                              "side": torch.cuda.Stream(dev), "fork": torch.cuda.Event(), "join": torch.cuda.Event()})
+                              "side": torch.cuda.Stream(dev), "fork0": torch.cuda.Event(), "fork": torch.cuda.Event(),
+                              "join": torch.cuda.Event()})
                 # The H0 chain (first layer of the rows -> G -> gather) and the D chain (D rows -> dY -> D) share only their
                 # inputs: both GEMMs are a few hundred tiles -- one or two rounds over the 256 CUs, the launch as long as its
                 # last round -- and the bookkeeping kernels are latency-bound, so the D chain runs on a SIDE STREAM beside the
