@@ -430,7 +430,9 @@ def dqn_leg(pkg, torch, dev, env):
             flop_total += st["flop"]
         elif st.get("bytes"):
             blocks[name] = hbm_block(st["kernel"], st["bytes"], st["us"] * 1e-6, note=st.get("note", ""))
-    dense_flop = 2.0 * T * (6 * 60 + 15 * 256) * 256 + sum(st["flop"] for k, st in stages.items() if k == "fc1_rows")
+    triples = stages.get("shared_need", {}).get("needed_triples")     # rows of the per-table form of D
+    dense_flop = 2.0 * T * (6 * 60 + 15 * 256) * 256 + (2.0 * triples * 256 * 256 if triples else
+                                                         sum(st["flop"] for k, st in stages.items() if k == "fc1_rows"))
     res["roofline"] = mfma_block("the whole iteration (all launches)", flop_total, per_iter,
                                  note="GEMM FLOP EXECUTED in one iteration / the iteration's wall time.  With shared rows (one row "
                                       "per distinct (rank, face column) of the batch) the count-0 term needs ~20 x fewer FLOP than its "

@@ -3695,18 +3695,19 @@ int ddz_q_shared_rows(ddz_env_t* e, void* ws, int64_t ws_bytes, int64_t row_capa
   return check_launch();
 }
 int ddz_q_features_rows(int device, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
-                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, const float* mz, float* g,
+                        const int32_t* rep, const int32_t* seg, float* ys, int64_t ys_ld, int64_t row_capacity, const float* mz, float* g,
                         void* stream) {
   if (!face || !wf || !bias || !rep || !seg || !ys || n_tables <= 0 || ((mz == nullptr) != (g == nullptr))) return DDZ_EINVAL;
+  if (ys_ld != QH && ys_ld != QH + 32) return DDZ_EINVAL;
   if (!al(mz, 4) || !al(g, 4)) return DDZ_EINVAL;
   if (!al(face, 16) || !al(wf, 4) || !al(bias, 4) || !al(rep, 4) || !al(seg, 4) || !al(ys, 4)) return DDZ_EINVAL;
-  if (row_capacity < QR_TILE || row_capacity % QR_TILE || row_capacity > (((int64_t)1 << 31) - 1) / QH || n_tables > ((int64_t)1 << 26))
+  if (row_capacity < QR_TILE || row_capacity % QR_TILE || row_capacity > (((int64_t)1 << 31) - 1) / (QH + 32) || n_tables > ((int64_t)1 << 26))
     return DDZ_ECAP;
   if (planes != 6) return DDZ_EINVAL;   // EnvCooperationSimplify's six planes: the only face whose columns ddz_q_shared_rows keys
   DeviceGuard gd(device);
   if (!gd.ok) return DDZ_ENODEV;
   hipLaunchKernelGGL(k_q_feat_rows<6>, dim3((unsigned)(row_capacity / QR_TILE)), dim3(QH), 0, (hipStream_t)stream, (const float4*)face,
-                     n_tables, wf, bias, rep, seg, ys, mz, g);
+                     n_tables, wf, bias, rep, seg, ys, (int)ys_ld, mz, g);
   return check_launch();
 }
 // the needed rows D shared as well (ddz_qnet.h section 6)
@@ -3766,14 +3767,16 @@ int ddz_q_gather_h0(int device, const float* g, int64_t g_rows, const int32_t* r
   return check_launch();
 }
 
-int ddz_q_fc1_rows_acc(int device, const float* y, const int32_t* seg, const float* w2, float* g, int64_t row_capacity, void* stream) {
-  if (!y || !seg || !w2 || !g) return DDZ_EINVAL;
-  if (!al(y, 16) || !al(w2, 16) || !al(g, 4) || !al(seg, 4)) return DDZ_EINVAL;
-  if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / QH) return DDZ_EINVAL;
+int ddz_q_fc1_rows_k(int device, const float* y, int64_t k, const int32_t* seg, const float* w2k, float* g, int64_t row_capacity,
+                      int accumulate, void* stream) {
+  if (!y || !seg || !w2k || !g) return DDZ_EINVAL;
+  if (!al(y, 16) || !al(w2k, 16) || !al(g, 4) || !al(seg, 4)) return DDZ_EINVAL;
+  if (k < FC_K || k % FC_K || k > 4096) return DDZ_EINVAL;
+  if (row_capacity < FC_M || row_capacity % FC_M || row_capacity > (((int64_t)1 << 31) - 1) / k) return DDZ_EINVAL;
   DeviceGuard gd(device);
   if (!gd.ok) return DDZ_ENODEV;
-  hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, y, (int64_t)QH, w2, g,
-                     (int64_t)0, QH, seg, (const float*)nullptr, (const uint8_t*)nullptr, 1);
+  hipLaunchKernelGGL(k_fc1<true>, dim3((unsigned)(row_capacity / FC_M)), dim3(FC_THREADS), 0, (hipStream_t)stream, y, k, w2k, g,
+                     (int64_t)0, (int)k, seg, (const float*)nullptr, (const uint8_t*)nullptr, accumulate ? 1 : 0);
   return check_launch();
 }
 

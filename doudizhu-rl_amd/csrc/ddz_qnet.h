@@ -392,7 +392,7 @@ __global__ __launch_bounds__(FC_THREADS, FC_OCC) void k_fc1(const float* __restr
     int r = 0;
 #pragma unroll
     for (int q = 1; q < 15; ++q) r += (int)blockIdx.x >= seg[16 + q];
-    B += (int64_t)r * QH * FC_N;
+    B += (int64_t)r * K * FC_N;     // (K rows per rank: 256, or 288 with the table term's 24 column rows appended -- section 5)
     M = seg[15];
     if (zfold)
       for (int i = tid; i < 5 * QH; i += FC_THREADS) sZ[i] = zfold[(int64_t)r * 5 * QH + i];   // (visible behind the first barrier)
@@ -732,8 +732,11 @@ constexpr int QR_TILE = 64;    // rows per block (128: fewer, longer blocks -- m
 template <int P>
 __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ face, int64_t T, const float* __restrict__ wf,
                                                     const float* __restrict__ bias, const int32_t* __restrict__ rep,
-                                                    const int32_t* __restrict__ seg, float* __restrict__ ys,
+                                                    const int32_t* __restrict__ seg, float* __restrict__ ys, int ys_ld,
                                                     const float* __restrict__ mz, float* __restrict__ g) {
+  // ys_ld > 256 (QS_K = 288): the row's 24 COLUMN values (plane-major, then 8 zeros) are appended behind its 256 first-layer
+  // values -- the table term (linear in the face) then is 24 more rows of the rank's fc1 block: ONE K = 288 GEMM gives
+  // G[row] = Y[row] x fc1[rank] + column x Mz[rank], nothing is accumulated (mz / g: the earlier form, kept).
   // mz / g (both or neither): the TABLE TERM folded into the rows -- the face part of conv_shunzi through fc1 is linear in the
   // face, i.e. a sum over the ranks of (column of rank r) x mz[rows p * 60 + 4 r + w] (mz f32 [P * 60][256], the operand of the
   // per-table GEMM [T, 60 P] x [60 P, 256] it replaces): g[row] = that product for the row's column and rank; the rows GEMM
@@ -783,7 +786,8 @@ __global__ __launch_bounds__(QH) void k_q_feat_rows(const float4* __restrict__ f
       s2 += w[p][3] * x.x + w[p][4] * x.y + w[p][5] * x.z;
       s3 += w[p][6] * x.x + w[p][7] * x.y + w[p][8] * x.z + w[p][9] * x.w;
     }
-    ys[(row0 + j) * QH + c] = s_ok[j] ? fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)) : 0.f;
+    ys[(row0 + j) * ys_ld + c] = s_ok[j] ? fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)) : 0.f;
+    if (c < ys_ld - QH) ys[(row0 + j) * ys_ld + QH + c] = c < 4 * P ? ((const float*)&s_col[j * P])[c] : 0.f;   // (zeros where !ok)
     if (g) {
       float lin = 0.f;
 #pragma unroll

@@ -224,6 +224,11 @@ class FactorisedQ:
         self.base = (n.fc1.bias + torch.einsum("ocw,c->o", W1z, n.conv_shunzi.bias)).contiguous()
         W2 = W1y.permute(2, 1, 0).contiguous()                         # [r, c, o]: fc1 per rank
         self.W2 = W2
+        # fc1 per rank with the table term's rows appended (the shared-rows form, csrc/ddz_qnet.h section 5): a shared row
+        # carries its 24 column values behind its 256 first-layer values, so [fc1_r ; Mz[:, r] ; 0] (K = 288) gives
+        # Y x fc1_r + column x Mz_r in one product
+        self.W2x = torch.cat([W2, Mz[:P].permute(1, 0, 2, 3).reshape(15, P * 4, H1),
+                              torch.zeros((15, 32 - P * 4, H1), dtype=dt, device=dev)], dim=1).contiguous() if P * 4 <= 32 else None
         self.Wd = W2.reshape(15 * H, H1)                               # the dense GEMM's right operand: K = 15 * 256, rank-major
         # one GEMM batch per (rank, count): ranks 3..2 have counts 0..4 (65 batches), the two jokers counts 0..1
         self.W2_main = W2[:13, None].expand(13, 5, H, H1).reshape(65, H, H1).contiguous()
@@ -427,15 +432,16 @@ class FactorisedQ:
                           "srows": torch.full((T, 16), -1, dtype=torch.int32, device=dev),
                           "srep": torch.full((scap,), -1, dtype=torch.int32, device=dev),
                           "sseg": torch.zeros(40, dtype=torch.int32, device=dev),
-                          "ys": torch.zeros((scap, H), dtype=torch.float32, device=dev),
+                          "ys": torch.zeros((scap, H + 32), dtype=torch.float32, device=dev),
                           "g": torch.zeros((scap, H1), dtype=torch.float32, device=dev)})
                 w["y0"] = None                                                     # (1 GB at 65,536 tables: not needed in this form)
             env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"])
 
             def h0_chain():
-                # G[row] = column x Mz[rank] (the table term is linear in the face: folded into the rows) + Y[row] x fc1[rank]
-                E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"], mz=self.Mz_f, g=w["g"])
-                E.q_fc1_rows_acc(w["ys"], w["sseg"], self.W2, w["g"])
+                # G[row] = Y[row] x fc1[rank] + column x Mz[rank] (the table term is linear in the face: folded into the rows --
+                # the column rides behind Y in the row, Mz[rank] behind fc1[rank] in the operand: one K = 288 product)
+                E.q_features_rows(face, self.Wf, self.bias_f, w["srep"], w["sseg"], w["ys"])
+                E.q_fc1_rows_k(w["ys"], w["sseg"], self.W2x, w["g"])
                 E.q_gather_h0(w["g"], w["srows"], w["h0"], base=self.base)        # H0[t] = base + sum_r G[row(t, r)]
 
             if shared == "all":      # the needed rows shared as well: one D row per distinct (shared row, count) (section 6)
@@ -766,8 +772,8 @@ class PolicyLoop:
             timed("need", lambda: env.q_need(w["cap"], w["scratch"], w["row_index"], w["seg"], w["row_cnt"]))
             if self.shared:
                 timed("shared_rows", lambda: env.q_shared_rows(w["sws"], w["scap"], w["srows"], w["srep"], w["sseg"]))
-                timed("features_shared", lambda: E.q_features_rows(self.face, fq.Wf, fq.bias_f, w["srep"], w["sseg"], w["ys"], mz=fq.Mz_f, g=w["g"]))
-                timed("fc1_shared", lambda: E.q_fc1_rows_acc(w["ys"], w["sseg"], fq.W2, w["g"]))
+                timed("features_shared", lambda: E.q_features_rows(self.face, fq.Wf, fq.bias_f, w["srep"], w["sseg"], w["ys"]))
+                timed("fc1_shared", lambda: E.q_fc1_rows_k(w["ys"], w["sseg"], fq.W2x, w["g"]))
                 timed("gather_h0", lambda: E.q_gather_h0(w["g"], w["srows"], w["h0"], base=fq.base))
                 if self.shared == "all":
                     timed("shared_need", lambda: env.q_shared_need(w["row_index"], w["srows"], w["sseg"], w["scap"], w["dws"], w["cap"],
@@ -807,17 +813,17 @@ class PolicyLoop:
                                 "bytes": T * 176 + 3 * 4134375 * 4 + T * 16 * 4 * 3 + rs * 8,
                                 "note": f"one row per distinct (rank, face column): {rs:.0f} of the {15 * T} columns ({rs / (15 * T):.3f}); "
                                         "state read, the 16.5-MB slot table cleared / counted / assigned, rows [T,16] written"},
-                "features_shared": {"us": us["features_shared"], "kernel": "k_q_feat_rows<6>", "bytes": rs * (P * 16 + 2 * H * 4),
+                "features_shared": {"us": us["features_shared"], "kernel": "k_q_feat_rows<6>", "bytes": rs * (P * 16 + (H + 32) * 4),
                                     "note": "first layer (count 0) of the shared rows + the table term of their columns (linear in the "
                                             "face: folded into the rows -- no [T, 360] x [360, 256] GEMM per iteration)"},
-                "fc1_shared": {"us": us["fc1_shared"], "kernel": "k_fc1<true>", "flop": 2.0 * rs * H * H,
-                               "note": f"G = Y x fc1[rank] over the {rs:.0f} shared rows ({rsp:.0f} with the padding of the fifteen "
+                "fc1_shared": {"us": us["fc1_shared"], "kernel": "k_fc1<true>", "flop": 2.0 * rs * (H + 32) * H,
+                               "note": f"G = [Y | column] x [fc1[rank] ; Mz[rank]] (K = 288) over the {rs:.0f} shared rows ({rsp:.0f} with the padding of the fifteen "
                                        f"segments) -- the dense form of the same term is 2 x {T} x 3840 x 256 = {2.0 * T * 15 * H * H / 1e9:.0f} GFLOP"},
                 "gather_h0": {"us": us["gather_h0"], "kernel": "k_qs_gather", "bytes": T * (64 + 2 * H * 4) + rs * H * 4,
                               "note": f"H0 read and written, rows [T,16] read, every row of G once ({rs * H * 4 / 1e6:.0f} MB: the fifteen "
                                       f"1-KB reads per table -- {T * 15 * H * 4 / 1e9:.2f} GB -- are served by L2 / MALL)"},
                 **({"shared_need": {"us": us["shared_need"], "kernel": "memset + k_qd_mark + k_qd_count + k_qd_seg + k_qd_assign + k_qd_remap",
-                                    "bytes": T * 64 * 4 * 3 + T * 64 + rs * 16 * 3 + rn * 5,
+                                    "bytes": T * 64 * 4 * 3 + T * 64 + rs * 16 * 3 + rn * 5, "needed_triples": rows_private / n,
                                     "note": f"one D row per distinct (shared row, count) some table needs: {rn:.0f} rows for the "
                                             f"{rows_private / n:.0f} needed (table, rank, count) triples ({rows_private / n / T:.2f} per table)"},
                     "features": {"us": us["features"], "kernel": "k_q_feat_drows<6>", "bytes": rn * (P * 16 + H * 4 + 8),

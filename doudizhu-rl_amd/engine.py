@@ -717,8 +717,8 @@ def q_features_rows(face, wf, bias, rep, seg, ys, mz=None, g=None):
     if face.dtype != torch.float32 or tuple(face.shape[1:]) != (6, 15, 4) or not face.is_contiguous():
         raise ValueError("face must be a contiguous float32 [T,6,15,4] tensor (EnvCooperationSimplify)")
     n = int(ys.shape[0])
-    if ys.dtype != torch.float32 or ys.dim() != 2 or ys.shape[1] != 256 or not ys.is_contiguous() or ys.device != dev:
-        raise ValueError("ys must be a contiguous float32 [rows,256] tensor on the same device")
+    if ys.dtype != torch.float32 or ys.dim() != 2 or ys.shape[1] not in (256, 288) or not ys.is_contiguous() or ys.device != dev:
+        raise ValueError("ys must be a contiguous float32 [rows,256] (or [rows,288]: + the column values) tensor on the same device")
     if rep.dtype != torch.int32 or rep.numel() < n or rep.device != dev or seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
         raise ValueError("rep must be int32 [rows], seg int32 [40], on the same device")
     for w, k in ((wf, P * 4 * 1024), (bias, 1024)):
@@ -729,21 +729,23 @@ def q_features_rows(face, wf, bias, rep, seg, ys, mz=None, g=None):
     if mz is not None and (mz.dtype != torch.float32 or tuple(mz.shape) != (P * 60, 256) or not mz.is_contiguous() or mz.device != dev
                            or g.dtype != torch.float32 or tuple(g.shape) != (n, 256) or not g.is_contiguous() or g.device != dev):
         raise ValueError("mz must be float32 [60 P, 256], g float32 [rows, 256], contiguous, on the same device")
-    check(L.ddz_q_features_rows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(rep), _p(seg), _p(ys), n, _p(mz), _p(g), _stream(dev)))
+    check(L.ddz_q_features_rows(dev.index, _p(face), T, P, _p(wf), _p(bias), _p(rep), _p(seg), _p(ys), int(ys.shape[1]), n, _p(mz), _p(g),
+                                _stream(dev)))
     return ys
 
 
-def q_fc1_rows_acc(y, seg, w2, g):
-    """ddz_q_fc1_rows_acc: g[row] += y[row] @ w2[rank of the row] for the rows / rank segments of seg (device int32 [40])."""
+def q_fc1_rows_k(y, seg, w2k, g, accumulate=False):
+    """ddz_q_fc1_rows_k: g[row] (+)= y[row] @ w2k[rank of the row] for the rows / rank segments of seg (device int32 [40]);
+    y f32 [rows,k], w2k f32 [15,k,256], k a multiple of 16."""
     L = _lib.lib()
     dev = _require_gpu(y.device)
-    n = int(y.shape[0])
-    for x, shp in ((y, (n, 256)), (g, (n, 256)), (w2, (15, 256, 256))):
+    n, k = int(y.shape[0]), int(y.shape[1])
+    for x, shp in ((y, (n, k)), (g, (n, 256)), (w2k, (15, k, 256))):
         if x.dtype != torch.float32 or tuple(x.shape) != shp or not x.is_contiguous() or x.device != dev:
-            raise ValueError("y / g [rows,256], w2 [15,256,256]: contiguous float32 tensors on one device")
+            raise ValueError("y [rows,k], g [rows,256], w2k [15,k,256]: contiguous float32 tensors on one device")
     if seg.dtype != torch.int32 or seg.numel() < 40 or seg.device != dev:
         raise ValueError("seg must be int32 [40] on the same device")
-    check(L.ddz_q_fc1_rows_acc(dev.index, _p(y), _p(seg), _p(w2), _p(g), n, _stream(dev)))
+    check(L.ddz_q_fc1_rows_k(dev.index, _p(y), k, _p(seg), _p(w2k), _p(g), n, 1 if accumulate else 0, _stream(dev)))
     return g
 
 

@@ -341,7 +341,7 @@ int ddz_q_slab_needed(ddz_env_t* env, const float* h0, const float* d, int64_t r
  *   segments, starts multiples of the tile).  row_capacity: a multiple of the tile, >= min(15 T, 4134375) + 15 tiles (then
  *   nothing can overflow).  ws: ddz_q_shared_ws_bytes() bytes (16.6 MB: one int32 slot per possible (rank, column)), 16-byte
  *   aligned, contents irrelevant on entry.  Row numbers follow the key order: deterministic.
- * ddz_q_features_rows: ys f32 [row_capacity][256] = first layer (count 0) of every row's column, read from `face` f32
+ * ddz_q_features_rows: ys f32 [row_capacity][ys_ld] (ys_ld 256 or 288) = first layer (count 0) of every row's column, read from `face` f32
  *   [T][6][15][4] at rep[row]; padding rows = 0.  planes must be 6.
  * ddz_q_gather_h0: h0 f32 [T][256] += sum over r = 0..14 (in this order) of g[rows[t][r]] (g f32 [g_rows][256]; rows < 0 or
  *   >= g_rows contribute nothing).
@@ -366,17 +366,19 @@ int64_t ddz_q_shared_ws_bytes(void);
 int ddz_q_shared_rows(ddz_env_t* env, void* ws, int64_t ws_bytes, int64_t row_capacity, int32_t* rows, int32_t* rep,
                       int32_t* seg, void* stream);
 int ddz_q_features_rows(int device_id, const float* face, int64_t n_tables, int planes, const float* wf, const float* bias,
-                        const int32_t* rep, const int32_t* seg, float* ys, int64_t row_capacity, const float* mz, float* g,
-                        void* stream);
+                        const int32_t* rep, const int32_t* seg, float* ys, int64_t ys_ld, int64_t row_capacity, const float* mz,
+                        float* g, void* stream);
 int ddz_q_gather_h0(int device_id, const float* g, int64_t g_rows, const int32_t* rows, int64_t n_tables, const float* base,
                     float* h0, void* stream);
 /* The table term folded into the rows: it is linear in the face (fc1 bias + the face part of conv_shunzi through fc1), i.e.
  * base + sum_r column_r x mz[p * 60 + 4 r + w] (mz f32 [60 * 6][256]: the operand of the [T, 360] x [360, 256] GEMM it
- * replaces).  ddz_q_features_rows with mz / g (both or neither) writes that product of every row's column into g
- * f32 [row_capacity][256]; ddz_q_fc1_rows_acc: g[row] += y[row] x w2[rank]; ddz_q_gather_h0 with base f32 [256] (or NULL:
- * h0 += ...): h0[t] = base + sum_r g[rows[t][r]]. */
-int ddz_q_fc1_rows_acc(int device_id, const float* y, const int32_t* seg, const float* w2, float* g, int64_t row_capacity,
-                       void* stream);
+ * replaces).  ddz_q_features_rows with ys_ld = 288 appends the row's 24 column values (plane-major; then 8 zeros) behind its
+ * 256 first-layer values; ddz_q_fc1_rows_k(k = 288): g[row] (+)= y[row] x w2k[rank] with w2k f32 [15][k][256] = fc1's block of
+ * the rank, then the rank's 24 rows of mz, then zeros -- ONE product per row gives both terms; ddz_q_gather_h0 with base f32
+ * [256] (or NULL: h0 += ...): h0[t] = base + sum_r g[rows[t][r]].  (ys_ld = 256 with mz / g: the product of the column is
+ * written into g instead and the GEMM accumulates -- the same values, one more pass over g.) */
+int ddz_q_fc1_rows_k(int device_id, const float* y, int64_t k, const int32_t* seg, const float* w2k, float* g,
+                     int64_t row_capacity, int accumulate, void* stream);
 
 /* The canonical action table: rows[ddz_num_actions()][16] = int8 counts[15] + category of action id
  * (rule_based/utils/card.py:34-159 order), device memory. */
