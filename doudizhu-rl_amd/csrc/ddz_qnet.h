@@ -647,7 +647,16 @@ __global__ __launch_bounds__(256) void k_qs_mark(const uint8_t* __restrict__ sta
   const int b1 = c4(row[(DDZ_F_RECENT0 + rm1) * 16 + r]), b2 = c4(row[(DDZ_F_RECENT0 + rp1) * 16 + r]);
   int n1 = row[(DDZ_F_HAND0 + rp1) * 16 + 15], n2 = row[(DDZ_F_HAND0 + rm1) * 16 + 15];
   n1 = n1 > 20 ? 20 : n1; n2 = n2 > 20 ? 20 : n2;
-  const int key = r * QSH_COLS + (((hand * 5 + taken) * 5 + b1) * 5 + b2) * 441 + n1 * 21 + n2;
+  // canonical (n1, n2): the prob planes hold n / (n1 + n2) -- the same float for (2, 4) and (1, 2) (one correctly rounded
+  // division of the same rational) -- and only in the slots known <= j < total: none when hand + taken >= total.  Halves the
+  // distinct rows (measured on the oracle's states: 86,689 -> 43,232 at 65,536 tables).
+  {
+    int g = n1, b = n2;
+    while (b) { const int m = g % b; g = b; b = m; }
+    if (g > 1) { n1 /= g; n2 /= g; }
+  }
+  const int ncode = hand + taken >= (r < 13 ? 4 : 1) ? 0 : n1 * 21 + n2;
+  const int key = r * QSH_COLS + (((hand * 5 + taken) * 5 + b1) * 5 + b2) * 441 + ncode;
   slots[key] = (int32_t)idx + 1;
   rows[idx] = key;
 }

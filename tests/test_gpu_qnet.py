@@ -142,14 +142,18 @@ def test_shared_rows_form_of_h0_equals_the_dense_form(pkg, T):
         assert bool((inst >= 0).all()) and bool(((inst & 15) == torch.arange(15)[None, :]).all())
         rep_cols = cols[(inst >> 4) * 15 + (inst & 15)]
         assert torch.equal(rep_cols, cols.view(T, 15, 6, 4))              # same column, bit for bit
-        # one row per distinct KEY (hand_r, taken_r, b1_r, b2_r, n1, n2) of a rank, numbered in key order; keys are at least as
-        # fine as columns (two keys may give one column: e.g. equal n1 / (n1 + n2)), never coarser (checked above)
+        # one row per distinct KEY (hand_r, taken_r, b1_r, b2_r, canonical (n1, n2)) of a rank, numbered in key order; keys are at
+        # least as fine as columns, never coarser (checked above: the representative's column is the instance's, bit for bit)
         st = env.state.cpu().view(T, 11, 16).long()
         role = st[:, 10, 0]
         ar = torch.arange(T)
         rm1, rp1 = (role + 2) % 3, (role + 1) % 3
-        key = ((((st[ar, role, :15] * 5 + st[:, 9, :15]) * 5 + st[ar, 6 + rm1, :15]) * 5 + st[ar, 6 + rp1, :15]) * 441
-               + (st[ar, rp1, 15] * 21 + st[ar, rm1, 15])[:, None])
+        n1, n2 = st[ar, rp1, 15], st[ar, rm1, 15]
+        gg = torch.gcd(n1, n2).clamp(min=1)                                  # canonical (n1, n2): n / (n1 + n2) is what the planes hold
+        total = torch.where(torch.arange(15) < 13, 4, 1)[None, :]
+        ncode = torch.where(st[ar, role, :15] + st[:, 9, :15] >= total, torch.zeros(1, dtype=torch.long),
+                            ((n1 // gg) * 21 + n2 // gg)[:, None])           # ... and only where known < total
+        key = ((((st[ar, role, :15] * 5 + st[:, 9, :15]) * 5 + st[ar, 6 + rm1, :15]) * 5 + st[ar, 6 + rp1, :15]) * 441 + ncode)
         n_rows = 0
         for r in range(15):
             uk, inv = torch.unique(key[:, r], return_inverse=True)          # sorted: the row order inside the segment
