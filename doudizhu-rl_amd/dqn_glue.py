@@ -386,11 +386,15 @@ class FactorisedQ:
         MFMA kernel (ddz_q_fc1_rows: a library GEMM would need the sizes on the host).  The dense GEMM (a plain
         [T, 3840] x [3840, 256] product) is torch.addmm = hipBLASLt by default (gemm="torch": 148 TFLOP/s in the loop), or
         the same MFMA kernel (gemm="mfma", ddz_q_fc1_dense: 125 TFLOP/s; six geometries measured, tools/fc1_probe.py).
-        shared=True (faces of EnvCooperationSimplify only, P = 6, and `face` MUST be env's variant-3 face of its current
-        states -- the rows are keyed from env's state): the SHARED-ROWS form of H0 (csrc/ddz_qnet.h section 5) -- no dense GEMM:
-        one row per distinct (rank, face column) of the batch (~5 % of the 15 T columns at 65,536 tables), first layer +
-        k_fc1 rows GEMM over those, H0[t] = table term + the fifteen rows of table t; the first layer of the needed rows then
-        skips the ranks no legal move touches.  Same values up to fp32 summation order (tests: 1e-5).
+        shared=True / "all" (faces of EnvCooperationSimplify only, P = 6, and `face` MUST be env's variant-3 face of its
+        current states -- the rows are keyed from env's state): the SHARED-ROWS form (csrc/ddz_qnet.h sections 5-6) -- no dense
+        GEMM: one row per distinct (rank, face column) of the batch (3.6 % of the 15 T columns at 65,536 tables), first layer +
+        ONE k_fc1 rows product over those (K = 288: the table term rides in it), H0[t] = base + the fifteen rows of table t.
+        True: the needed rows D stay per table (their first layer skips the ranks no legal move touches); "all" (PolicyLoop's
+        default): D as well once per distinct (shared row, count) -- the returned row_index is then the remapped one -- and the
+        D chain runs on a side stream beside the H0 chain (self.two_streams; fork / join by events, no host synchronisation).
+        Exact per call from the current weights and states (nothing is cached between calls); same values up to fp32 summation
+        order in H0 (tests: 1e-5; D and q bit for bit between True and "all").
         The result aliases this object's workspace: consume it before the next call."""
         from . import engine as E
         if self._ver != self._versions():
