@@ -332,7 +332,8 @@ int ddz_q_slab_needed(ddz_env_t* env, const float* h0, const float* d, int64_t r
 
 /* H0 from SHARED rows (doudizhu-rl_amd/csrc/ddz_qnet.h section 5; the same forward, net.py:81-102, for faces of
  * EnvCooperationSimplify, envi.py:201-217): Y[t][r][0] depends only on the face column of rank r, i.e. on (hand_r, taken_r,
- * b1_r, b2_r, n1, n2), and across the tables of a batch those columns repeat (~5 % distinct at 65,536 tables).  One row per
+ * b1_r, b2_r) and -- through n / (n1 + n2), and only where hand_r + taken_r < total -- on (n1, n2) reduced by their gcd; across
+ * the tables of a batch those columns repeat (3.6 % distinct at 65,536 tables).  One row per
  * DISTINCT (rank, column): first layer + G[row] = Y[row] x fc1[rank] (ddz_q_fc1_rows with z = row_cnt = NULL), then
  * H0[t] = table_term[t] + sum_r G[rows[t][r]] -- instead of the K = 15 * 256 dense product.  Exact per call (nothing is kept
  * between calls), equal to the dense form up to fp32 summation order.
