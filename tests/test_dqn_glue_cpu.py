@@ -355,3 +355,36 @@ def test_epsilon_schedule_and_checkpoint_dirs_as_the_reference_computes_them(gol
     assert [float(x) for x in g["hyper"]] == [glue.EPSILON_HIGH, glue.EPSILON_LOW, 20000.0, 256.0, float(glue.DECAY), 20.0]
     for n, d2, d1 in zip(g["name_dir_in"], g["name_dir_out"], g["name_dir_out_split1"]):
         assert metrics.name_dir(str(n)) == str(d2) and metrics.name_dir(str(n), 1) == str(d1)
+
+
+def test_shared_row_key_determines_the_face_column(oracle):
+    """The key of the shared-rows Q forward (csrc/ddz_qnet.h section 5, k_qs_mark): (rank, hand_r, taken_r, b1_r, b2_r) and the
+    pair (n1, n2) reduced by its gcd -- 0 where hand_r + taken_r >= total (no prob slot is set) -- must DETERMINE the face
+    column of EnvCooperationSimplify (envi.py:201-217): on random mid-game states of the oracle env, all (table, rank)
+    instances with one key have bit-identical columns of the oracle's `face` (so one first-layer / fc1 row serves them all)."""
+    T = 4096
+    env = oracle.OracleEnv(T, seed=77)
+    env.reset()
+    seen = {}
+    for rounds in (0, 9, 23, 41, 66):
+        if rounds:
+            env.rollout_random(rounds)
+        face = env.observe(3)                                            # [T, 6, 15, 4]
+        cols = np.ascontiguousarray(face.transpose(0, 2, 1, 3)).reshape(T, 15, 24)
+        st = np.asarray(env.state).reshape(T, 11, 16).astype(np.int64)
+        role = st[:, 10, 0]
+        ar = np.arange(T)
+        rm1, rp1 = (role + 2) % 3, (role + 1) % 3
+        hand, taken = st[ar, role, :15], st[:, 9, :15]
+        b1, b2 = st[ar, 6 + rm1, :15], st[ar, 6 + rp1, :15]
+        n1, n2 = st[ar, rp1, 15], st[ar, rm1, 15]
+        g = np.gcd(n1, n2)
+        g[g == 0] = 1
+        total = np.where(np.arange(15) < 13, 4, 1)[None, :]
+        ncode = np.where(hand + taken >= total, 0, ((n1 // g) * 21 + n2 // g)[:, None])
+        key = ((((np.arange(15)[None, :] * 5 + hand) * 5 + taken) * 5 + b1) * 5 + b2) * 441 + ncode
+        assert key.max() < 15 * 625 * 441
+        for k, c in zip(key.reshape(-1).tolist(), cols.reshape(-1, 24)):
+            b = c.tobytes()
+            assert seen.setdefault(k, b) == b                            # one key, one column -- across tables AND states
+    assert len(seen) > 2000                                              # (and the states were varied enough to mean something)
