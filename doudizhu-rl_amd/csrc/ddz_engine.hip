@@ -3792,7 +3792,10 @@ int ddz_q_slab_needed(ddz_env_t* e, const float* h0, const float* d, int64_t row
   // (64 tables per block at most: the blocks are the unit the hardware balances over the CUs, the tables inside a block are
   // handed out by an LDS ticket)
   int64_t v = (e->T + 4095) / 4096;
-  const int tpw = (int)(v < 1 ? 1 : v > 4 ? 4 : v);
+  int tpw = (int)(v < 1 ? 1 : v > 4 ? 4 : v);
+#ifdef DDZ_QS_TPW_ENV   // (a timing experiment: tables per wave of the row stage from the environment; tools/row_stage_probe.py)
+  if (const char* s_ = getenv("DDZ_QS_TPW")) { const int x = atoi(s_); if (x >= 1 && x <= 8) tpw = x; }
+#endif
   const int64_t per_block = (int64_t)WPB * tpw;
   hipLaunchKernelGGL(k_q_slab_needed, dim3((unsigned)((e->T + per_block - 1) / per_block)), dim3(TB), 0, (hipStream_t)stream,
                      (const float4*)h0, (const float4*)d, row_capacity, e->T, tpw, (const float4*)w2, b2, counts,
